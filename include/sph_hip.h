@@ -1,0 +1,198 @@
+/*
+ * sph_hip.h -- C ABI of libsph_hip, the MI355X (gfx950) engine for the SPH frame step.
+ *
+ * Every entry point replaces one use of UnityEngine.ComputeShader / ComputeBuffer in the
+ * reference host driver Assets/SPH.cs (citations are "SPH.cs:line") or one kernel of
+ * Assets/SPHCompute.compute ("compute:line").  Plain pointers and sizes only; no C++ or
+ * torch types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns int: 0 = SPH_OK, <0 = SPH_E_*; nothing throws or aborts.
+ *   - one ctx = one GPU = one owner thread at a time.  Calls enqueue on the ctx's HIP
+ *     stream and return; only download / read_counter / get_timings / synchronize block.
+ *   - the library owns all device memory; the caller owns every host pointer it passes.
+ *   - particle records at the boundary are the reference's 72-byte AoS struct
+ *     (compute:26-37, SPH.cs:54-65): 18 x fp32
+ *       pos[0..2] vel[3..5] acc[6..8] density[9] pressure[10] restDensity[11]
+ *       viscosity[12] mass[13] color[14..17]
+ *     always in ORIGINAL particle-id order, whatever order the engine keeps internally.
+ */
+#ifndef SPH_HIP_H
+#define SPH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPH_OK              0
+#define SPH_E_INVALID      -1   /* bad argument / bad state (message in sph_last_error) */
+#define SPH_E_NOMEM        -2   /* device or host allocation failed                     */
+#define SPH_E_HIP          -3   /* a HIP runtime call failed                            */
+#define SPH_E_NO_DEVICE    -4   /* no usable gfx950 device                              */
+#define SPH_E_STATE        -5   /* call order violated (e.g. density before grid build) */
+
+#define SPH_PARTICLE_FLOATS 18
+#define SPH_PARTICLE_BYTES  72
+
+/* Kernel ids = "#pragma kernel" order of the reference (compute:9-17); these are the
+ * values ComputeShader.FindKernel returns in SPH.cs:366-377. */
+enum sph_kernel {
+    SPH_K_CLEAR            = 0,  /* CS_Clear            compute:87-98   */
+    SPH_K_CLEAR_GRID       = 1,  /* CS_ClearGrid        compute:104-111 */
+    SPH_K_BUILD_GRID       = 2,  /* CS_BuildGrid        compute:117-136 */
+    SPH_K_DENSITY_PRESSURE = 3,  /* CS_DensityPressure  compute:142-193 */
+    SPH_K_FORCE_XSPH       = 4,  /* CS_ForceXSPH        compute:199-303 */
+    SPH_K_VV_HALF_STEP     = 5,  /* CS_VvHalfStep       compute:309-319 */
+    SPH_K_VV_FULL_STEP     = 6,  /* CS_VvFullStep       compute:325-334 */
+    SPH_K_BOUND_OBS        = 7,  /* CS_BoundObs         compute:340-486 */
+    SPH_K_VELOCITY_DAMPING = 8,  /* CS_VelocityDamping  compute:492-509 */
+    SPH_K_COUNT            = 9
+};
+
+/* Field-for-field mirror of "cbuffer SimulationParams" (compute:47-81), in declaration
+ * order, as filled by SPH.SetComputeParams (SPH.cs:379-412), UpdateObstacle (348-361) and
+ * the _DeltaTime upload (208).  Matrices are row-major M[r*4+c] and act on column vectors,
+ * i.e. mul(M, v)[r] = sum_c M[r*4+c] * v[c]  (compute:351, 396, 408). */
+typedef struct sph_params {
+    uint32_t struct_size;               /* = sizeof(sph_params); versioning            */
+    int32_t  particleCount;             /* _ParticleCount                              */
+    float    deltaTime;                 /* _DeltaTime                                  */
+    float    particleMass;              /* _ParticleMass   (declared, read by no kernel) */
+    float    restDensity;               /* _RestDensity    (declared, read by no kernel) */
+    float    soundSpeed;                /* _SoundSpeed                                 */
+    float    gamma;                     /* _Gamma                                      */
+    float    smoothingRadius;           /* _SmoothingRadius                            */
+    float    gravity;                   /* _Gravity                                    */
+    float    surfaceTensionCoefficient; /* _SurfaceTensionCoefficient                  */
+    float    surfaceTensionThreshold;   /* _SurfaceTensionThreshold                    */
+    float    xsphEpsilon;               /* _XSPHEpsilon                                */
+    float    particleCollisionDamping;  /* _ParticleCollisionDamping                   */
+    float    obstacleRepulsionStiffness;/* _ObstacleRepulsionStiffness (read by no kernel) */
+    float    obstacleRadius;            /* _ObstacleRadius                             */
+    float    boundsCenter[3];           /* _BoundsCenter   (AABB branch only)          */
+    float    boundsSize[3];             /* _BoundsSize     (AABB branch only)          */
+    float    spawnCenter[3];            /* _SpawnCenter    (read by no kernel)         */
+    float    spawnSize[3];              /* _SpawnSize      (read by no kernel)         */
+    float    obstaclePos[3];            /* _ObstaclePos                                */
+    int32_t  gridResolutionX;           /* _GridResolutionX                            */
+    int32_t  gridResolutionY;           /* _GridResolutionY                            */
+    int32_t  gridResolutionZ;           /* _GridResolutionZ                            */
+    int32_t  maxParticlesPerCell;       /* _MaxParticlesPerCell                        */
+    float    cellSize;                  /* _CellSize                                   */
+    float    minBound[3];               /* _MinBound                                   */
+    float    boundaryMatrix[16];        /* _BoundaryMatrix    (cube localToWorld)      */
+    float    boundaryInvMatrix[16];     /* _BoundaryInvMatrix (cube worldToLocal)      */
+    float    boundaryHalfExtents[3];    /* _BoundaryHalfExtents: only |.|>0.001 is read,
+                                           as the OBB/AABB mode flag (compute:349)     */
+} sph_params;
+
+/* One spawn box's static per-particle properties (SpawnBox.cs:10-23); the device-resident
+ * stand-in for the arrays SPH.UpdateParticleStaticProperties rewrites (SPH.cs:284-298). */
+typedef struct sph_phase {
+    float restDensity;
+    float viscosity;
+    float mass;
+    float color[4];
+} sph_phase;
+
+/* Soft-fault / statistics words (never errors). */
+enum sph_counter {
+    SPH_CTR_COLLISIONS   = 0, /* CollisionCounter[0] (compute:418); zeroed by sph_reset_counter */
+    SPH_CTR_BIN_OVERFLOW = 1, /* #cells whose population exceeded maxParticlesPerCell at the
+                                 last grid build (compute:131 drops those ids)            */
+    SPH_CTR_OUT_OF_GRID  = 2, /* #particles whose unclamped cell was outside the grid at
+                                 the last grid build (compute:126 clamps them)            */
+    SPH_CTR_COUNT        = 3
+};
+
+typedef struct sph_ctx sph_ctx;
+
+/* Per-stage device time of the most recent sph_step_frame, in milliseconds (hipEvent). */
+typedef struct sph_timings {
+    float build_grid_ms;   /* hash + radix sort + ranges + reorder                */
+    float half_step_ms;
+    float density_ms;
+    float force_ms;
+    float full_step_ms;    /* full step (+ bound/obstacle when fused)            */
+    float bound_obs_ms;
+    float damping_ms;
+    float frame_ms;        /* whole frame, first launch to last                   */
+} sph_timings;
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+/* Replaces the implicit device of the Unity player.  device_id = HIP ordinal. */
+int  sph_create(sph_ctx** out, int device_id);
+/* SPH.OnDestroy (SPH.cs:235-241): ComputeBuffer.Release x4. */
+int  sph_destroy(sph_ctx* ctx);
+const char* sph_last_error(const sph_ctx* ctx);
+/* Human-readable build info ("gfx950 ..."); never NULL. */
+const char* sph_version(void);
+
+/* ---- particle buffer ("new ComputeBuffer(N, 72)", SetData, GetData) ----------------------- */
+/* SPH.cs:248-249  new ComputeBuffer(particleCount, 18*4). */
+int  sph_alloc_particles(sph_ctx* ctx, int n);
+/* SPH.cs:280 / 297  particleBuffer.SetData(array): n records of 72 B in id order. */
+int  sph_upload_particles(sph_ctx* ctx, const void* aos72, int n);
+/* SPH.cs:287  particleBuffer.GetData(array): n records of 72 B, id order.  Synchronises. */
+int  sph_download_particles(sph_ctx* ctx, void* aos72, int n);
+
+/* ---- grid buffers ---------------------------------------------------------------------- */
+/* SPH.cs:156-157 / 339-345: (re)allocation of GridCounts[cells] and GridIndices[cells*cap].
+ * The engine keeps cellStart/cellEnd[cells] + a sorted id list instead (no cells*cap array). */
+int  sph_resize_grid(sph_ctx* ctx, int rx, int ry, int rz, int max_per_cell);
+
+/* ---- parameters ------------------------------------------------------------------------ */
+/* SPH.cs:379-412 SetComputeParams + 348-361 UpdateObstacle + 208 SetFloat("_DeltaTime"). */
+int  sph_set_params(sph_ctx* ctx, const sph_params* p);
+/* SPH.cs:208  sphCompute.SetFloat("_DeltaTime", dtSub) on its own. */
+int  sph_set_delta_time(sph_ctx* ctx, float dt);
+
+/* ---- static per-particle properties (SPH.cs:284-298 without the PCIe round trip) -------- */
+int  sph_set_phase_table(sph_ctx* ctx, const sph_phase* table, int n_phases);
+/* particleSpawnBoxIndices (SPH.cs:75, 276): one phase index per particle id. */
+int  sph_set_phase_ids(sph_ctx* ctx, const uint8_t* ids, int n);
+/* Applies table[phase[id]] to restDensity/viscosity/mass/color of every particle now
+ * (what UpdateParticleStaticProperties does each frame). */
+int  sph_apply_phase_table(sph_ctx* ctx);
+
+/* ---- dispatch -------------------------------------------------------------------------- */
+/* SPH.DispatchCompute(kernel, count) (SPH.cs:439-443).  count must be the particle count
+ * (or the cell count for SPH_K_CLEAR_GRID), as SPH.cs always passes. */
+int  sph_dispatch(sph_ctx* ctx, int kernel_id, int count);
+/* The body of SPH.Update from ClearGrid to VelocityDamping (SPH.cs:201-222) in one call,
+ * with the same stage order; sets _DeltaTime = timeStep / subSteps itself (SPH.cs:207-208). */
+int  sph_step_frame(sph_ctx* ctx, int sub_steps, float time_step);
+/* Block until everything enqueued on the ctx's stream has finished. */
+int  sph_synchronize(sph_ctx* ctx);
+
+/* ---- counters (CollisionCounter, SPH.cs:158, 190) ---------------------------------------- */
+int  sph_reset_counter(sph_ctx* ctx, int which);            /* SetData({0}) SPH.cs:190 */
+int  sph_read_counter(sph_ctx* ctx, int which, int* value); /* synchronises            */
+
+/* ---- parity / debug exports (no reference counterpart; used by tests and the harness) ---- */
+/* State of the last grid build.  Any pointer may be NULL.
+ *   cell_start/cell_end[cells] : range of the cell in sorted order (equal when empty);
+ *                                 cell_end-cell_start = GridCounts[cell] (compute:130)
+ *   sorted_ids[n]               : particle ids by (cell, id): the concatenation of the
+ *                                 reference's bins when each is filled in ascending id
+ *   cell_of_particle[n]         : clamped linear cell index per particle id (compute:125-127) */
+int  sph_download_grid(sph_ctx* ctx, int32_t* cell_start, int32_t* cell_end,
+                       int32_t* sorted_ids, uint32_t* cell_of_particle);
+/* Neighbour lists as CS_DensityPressure would visit them NOW (current positions, current
+ * grid): for particle id i, the ids j != i with rSq < h2 in visiting order (z,y,x cells,
+ * then bin order; compute:158-181).  counts[n]; lists[n*max_neighbors], entries beyond
+ * counts[i] are set to -1; counts[i] may exceed max_neighbors (then the list is truncated). */
+int  sph_download_neighbors(sph_ctx* ctx, int32_t* counts, int32_t* lists, int max_neighbors);
+int  sph_get_timings(sph_ctx* ctx, sph_timings* out);
+/* Raw device pointers of the internal SoA buffers, for zero-copy views (torch, RCCL).
+ * name: "posM" "velV" "acc" "rhoP" "rho0" "origId".  Valid until the next alloc/destroy. */
+int  sph_device_pointer(sph_ctx* ctx, const char* name, void** ptr, uint64_t* bytes);
+/* The HIP stream the ctx enqueues on (hipStream_t as void*). */
+int  sph_get_stream(sph_ctx* ctx, void** stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPH_HIP_H */

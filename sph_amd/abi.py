@@ -1,0 +1,286 @@
+"""ctypes binding of the C ABI in include/sph_hip.h (libsph_hip.so).
+
+This is the reference-side binding a maintainer would write for Assets/SPH.cs, in Python:
+`Engine` plays the part of UnityEngine.ComputeShader + ComputeBuffer (SPH.cs:366-443).
+There is no CPU fallback: if the shared library is missing, importing the engine raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+PARTICLE_FLOATS = 18
+PARTICLE_BYTES = 72
+
+# enum sph_kernel == "#pragma kernel" order (compute:9-17)
+K_CLEAR, K_CLEAR_GRID, K_BUILD_GRID, K_DENSITY_PRESSURE, K_FORCE_XSPH, K_VV_HALF_STEP, \
+    K_VV_FULL_STEP, K_BOUND_OBS, K_VELOCITY_DAMPING = range(9)
+KERNEL_NAMES = ["CS_Clear", "CS_ClearGrid", "CS_BuildGrid", "CS_DensityPressure", "CS_ForceXSPH",
+                "CS_VvHalfStep", "CS_VvFullStep", "CS_BoundObs", "CS_VelocityDamping"]
+
+CTR_COLLISIONS, CTR_BIN_OVERFLOW, CTR_OUT_OF_GRID = range(3)
+
+# every symbol include/sph_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "sph_create", "sph_destroy", "sph_last_error", "sph_version", "sph_alloc_particles",
+    "sph_upload_particles", "sph_download_particles", "sph_resize_grid", "sph_set_params",
+    "sph_set_delta_time", "sph_set_phase_table", "sph_set_phase_ids", "sph_apply_phase_table",
+    "sph_dispatch", "sph_step_frame", "sph_synchronize", "sph_reset_counter", "sph_read_counter",
+    "sph_download_grid", "sph_download_neighbors", "sph_get_timings", "sph_device_pointer",
+    "sph_get_stream",
+]
+
+
+class SphParams(C.Structure):
+    """struct sph_params: field-for-field mirror of cbuffer SimulationParams (compute:47-81)."""
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("particleCount", C.c_int32),
+        ("deltaTime", C.c_float),
+        ("particleMass", C.c_float),
+        ("restDensity", C.c_float),
+        ("soundSpeed", C.c_float),
+        ("gamma", C.c_float),
+        ("smoothingRadius", C.c_float),
+        ("gravity", C.c_float),
+        ("surfaceTensionCoefficient", C.c_float),
+        ("surfaceTensionThreshold", C.c_float),
+        ("xsphEpsilon", C.c_float),
+        ("particleCollisionDamping", C.c_float),
+        ("obstacleRepulsionStiffness", C.c_float),
+        ("obstacleRadius", C.c_float),
+        ("boundsCenter", C.c_float * 3),
+        ("boundsSize", C.c_float * 3),
+        ("spawnCenter", C.c_float * 3),
+        ("spawnSize", C.c_float * 3),
+        ("obstaclePos", C.c_float * 3),
+        ("gridResolutionX", C.c_int32),
+        ("gridResolutionY", C.c_int32),
+        ("gridResolutionZ", C.c_int32),
+        ("maxParticlesPerCell", C.c_int32),
+        ("cellSize", C.c_float),
+        ("minBound", C.c_float * 3),
+        ("boundaryMatrix", C.c_float * 16),
+        ("boundaryInvMatrix", C.c_float * 16),
+        ("boundaryHalfExtents", C.c_float * 3),
+    ]
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.struct_size = C.sizeof(SphParams)
+        for k, v in kw.items():
+            self.set(k, v)
+
+    def set(self, name, value):
+        cur = getattr(self, name)
+        if isinstance(cur, C.Array):
+            flat = np.asarray(value, dtype=np.float32).reshape(-1)
+            if flat.size != len(cur):
+                raise ValueError(f"{name}: expected {len(cur)} floats, got {flat.size}")
+            for i, x in enumerate(flat):
+                cur[i] = float(x)
+        else:
+            setattr(self, name, value)
+
+    def copy(self):
+        other = SphParams()
+        C.memmove(C.byref(other), C.byref(self), C.sizeof(SphParams))
+        return other
+
+
+class SphPhase(C.Structure):
+    """struct sph_phase: one spawn box's static properties (SpawnBox.cs:10-23)."""
+    _fields_ = [("restDensity", C.c_float), ("viscosity", C.c_float), ("mass", C.c_float),
+                ("color", C.c_float * 4)]
+
+
+class SphTimings(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("build_grid_ms", "half_step_ms", "density_ms", "force_ms",
+                                         "full_step_ms", "bound_obs_ms", "damping_ms", "frame_ms")]
+
+
+def phase_array(phases):
+    """[(restDensity, viscosity, mass, (r,g,b,a)), ...] -> ctypes array of sph_phase."""
+    arr = (SphPhase * len(phases))()
+    for i, (rd, visc, mass, col) in enumerate(phases):
+        arr[i].restDensity, arr[i].viscosity, arr[i].mass = float(rd), float(visc), float(mass)
+        for k in range(4):
+            arr[i].color[k] = float(col[k])
+    return arr
+
+
+class SphError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libsph_hip error {code}: {msg}")
+        self.code = code
+
+
+_LIB = None
+
+
+def library_path() -> str:
+    return os.environ.get("SPH_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                         "libsph_hip.so")
+
+
+def load_library() -> C.CDLL:
+    """dlopen libsph_hip.so and declare prototypes.  Raises if it is not built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the engine has no CPU fallback)")
+    lib = C.CDLL(path)
+    vp, ip = C.c_void_p, C.c_int
+    lib.sph_create.argtypes = [C.POINTER(vp), ip]
+    lib.sph_destroy.argtypes = [vp]
+    lib.sph_last_error.argtypes = [vp]
+    lib.sph_last_error.restype = C.c_char_p
+    lib.sph_version.restype = C.c_char_p
+    lib.sph_alloc_particles.argtypes = [vp, ip]
+    lib.sph_upload_particles.argtypes = [vp, vp, ip]
+    lib.sph_download_particles.argtypes = [vp, vp, ip]
+    lib.sph_resize_grid.argtypes = [vp, ip, ip, ip, ip]
+    lib.sph_set_params.argtypes = [vp, C.POINTER(SphParams)]
+    lib.sph_set_delta_time.argtypes = [vp, C.c_float]
+    lib.sph_set_phase_table.argtypes = [vp, C.POINTER(SphPhase), ip]
+    lib.sph_set_phase_ids.argtypes = [vp, vp, ip]
+    lib.sph_apply_phase_table.argtypes = [vp]
+    lib.sph_dispatch.argtypes = [vp, ip, ip]
+    lib.sph_step_frame.argtypes = [vp, ip, C.c_float]
+    lib.sph_synchronize.argtypes = [vp]
+    lib.sph_reset_counter.argtypes = [vp, ip]
+    lib.sph_read_counter.argtypes = [vp, ip, C.POINTER(ip)]
+    lib.sph_download_grid.argtypes = [vp, vp, vp, vp, vp]
+    lib.sph_download_neighbors.argtypes = [vp, vp, vp, ip]
+    lib.sph_get_timings.argtypes = [vp, C.POINTER(SphTimings)]
+    lib.sph_device_pointer.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)]
+    lib.sph_get_stream.argtypes = [vp, C.POINTER(vp)]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("sph_last_error", "sph_version"):
+            fn.restype = ip
+    _LIB = lib
+    return lib
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One GPU's SPH engine (an sph_ctx).  Method names follow the C ABI."""
+
+    def __init__(self, device_id: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.sph_create(C.byref(h), device_id)
+        if rc != 0:
+            raise SphError(rc, "sph_create failed (no gfx950 device visible?)")
+        self.h = h
+        self.n = 0
+        self.cells = 0
+
+    # -- plumbing
+    def _ck(self, rc):
+        if rc != 0:
+            raise SphError(rc, self.lib.sph_last_error(self.h).decode())
+
+    def destroy(self):
+        if getattr(self, "h", None):
+            self.lib.sph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    # -- buffers
+    def alloc_particles(self, n):
+        self._ck(self.lib.sph_alloc_particles(self.h, n))
+        self.n = n
+
+    def upload_particles(self, aos: np.ndarray):
+        aos = np.ascontiguousarray(aos, dtype=np.float32).reshape(-1, PARTICLE_FLOATS)
+        self._ck(self.lib.sph_upload_particles(self.h, _ptr(aos), aos.shape[0]))
+
+    def download_particles(self) -> np.ndarray:
+        out = np.empty((self.n, PARTICLE_FLOATS), dtype=np.float32)
+        self._ck(self.lib.sph_download_particles(self.h, _ptr(out), self.n))
+        return out
+
+    def resize_grid(self, rx, ry, rz, cap):
+        self._ck(self.lib.sph_resize_grid(self.h, rx, ry, rz, cap))
+        self.cells = rx * ry * rz
+
+    def set_params(self, p: SphParams):
+        self._ck(self.lib.sph_set_params(self.h, C.byref(p)))
+
+    def set_delta_time(self, dt):
+        self._ck(self.lib.sph_set_delta_time(self.h, float(dt)))
+
+    def set_phase_table(self, phases):
+        arr = phases if isinstance(phases, C.Array) else phase_array(phases)
+        self._ck(self.lib.sph_set_phase_table(self.h, arr, len(arr)))
+
+    def set_phase_ids(self, ids: np.ndarray):
+        ids = np.ascontiguousarray(ids, dtype=np.uint8)
+        self._ck(self.lib.sph_set_phase_ids(self.h, _ptr(ids), ids.size))
+
+    def apply_phase_table(self):
+        self._ck(self.lib.sph_apply_phase_table(self.h))
+
+    # -- dispatch
+    def dispatch(self, kernel_id, count):
+        self._ck(self.lib.sph_dispatch(self.h, kernel_id, count))
+
+    def step_frame(self, sub_steps, time_step):
+        self._ck(self.lib.sph_step_frame(self.h, sub_steps, float(time_step)))
+
+    def synchronize(self):
+        self._ck(self.lib.sph_synchronize(self.h))
+
+    # -- counters
+    def reset_counter(self, which=CTR_COLLISIONS):
+        self._ck(self.lib.sph_reset_counter(self.h, which))
+
+    def read_counter(self, which=CTR_COLLISIONS) -> int:
+        v = C.c_int(0)
+        self._ck(self.lib.sph_read_counter(self.h, which, C.byref(v)))
+        return v.value
+
+    # -- parity exports
+    def download_grid(self):
+        cs = np.empty(self.cells, dtype=np.int32)
+        ce = np.empty(self.cells, dtype=np.int32)
+        ids = np.empty(self.n, dtype=np.int32)
+        cop = np.empty(self.n, dtype=np.uint32)
+        self._ck(self.lib.sph_download_grid(self.h, _ptr(cs), _ptr(ce), _ptr(ids), _ptr(cop)))
+        return cs, ce, ids, cop
+
+    def download_neighbors(self, max_neighbors):
+        counts = np.empty(self.n, dtype=np.int32)
+        lists = np.full((self.n, max_neighbors), -1, dtype=np.int32)
+        self._ck(self.lib.sph_download_neighbors(self.h, _ptr(counts), _ptr(lists), max_neighbors))
+        return counts, lists
+
+    def get_timings(self) -> dict:
+        t = SphTimings()
+        self._ck(self.lib.sph_get_timings(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in SphTimings._fields_}
+
+    def device_pointer(self, name: str):
+        p, b = C.c_void_p(), C.c_uint64()
+        self._ck(self.lib.sph_device_pointer(self.h, name.encode(), C.byref(p), C.byref(b)))
+        return p.value, b.value
+
+    def get_stream(self) -> int:
+        s = C.c_void_p()
+        self._ck(self.lib.sph_get_stream(self.h, C.byref(s)))
+        return s.value or 0

@@ -1,0 +1,669 @@
+// libsph_hip.hip -- the C ABI of include/sph_hip.h over the gfx950 kernels.
+//
+// Host side of the drop-in boundary: what UnityEngine.ComputeShader / ComputeBuffer do for
+// Assets/SPH.cs (FindKernel / Set* / SetBuffer / Dispatch / SetData / GetData / Release) is done
+// here over HIP.  No CPU fallback exists: without a gfx950 device sph_create fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "physics_kernels.h"
+
+using namespace sph;
+
+namespace {
+
+constexpr int kNumEvents = 10;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct sph_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    int n = 0;            // particle count
+    int capacity = 0;     // allocated particle capacity
+    StateSet set[2] = {};
+    int cur = 0;          // set[cur] holds posM/acc/rhoP/rho0/origId; velCur picks velV
+    int velCur = 0;
+    float4* color = nullptr;       // by id
+    uint8_t* phaseOfId = nullptr;  // by id
+    bool havePhaseIds = false;
+    sph_phase* phaseTableDev = nullptr;
+    std::vector<sph_phase> phaseTable;
+    bool staticDirty = false;
+
+    // grid
+    int rx = 0, ry = 0, rz = 0, cap = 0;
+    long long cells = 0;
+    long long cellCapacity = 0;
+    int* cellStart = nullptr;
+    int* cellEnd = nullptr;
+    uint32_t* keys[2] = {nullptr, nullptr};
+    uint32_t* vals[2] = {nullptr, nullptr};
+    uint32_t* sid = nullptr;
+    uint32_t* perm2 = nullptr;
+    uint32_t* blockHist = nullptr;
+    size_t blockHistElems = 0;
+    uint32_t* digitTotal = nullptr;
+    uint32_t* sortedKeys = nullptr;   // alias into keys[] after the last build
+    bool gridValid = false;
+
+    int* counters = nullptr;          // SPH_CTR_COUNT ints on the device
+    float* aosStage = nullptr;        // device AoS staging (n * 72 B)
+    void* pinned = nullptr;           // pinned host staging
+    size_t pinnedBytes = 0;
+
+    sph_params prm{};
+    bool haveParams = false;
+    DevParams dp{};
+
+    hipEvent_t ev[kNumEvents] = {};
+    bool timingsValid = false;
+};
+
+namespace {
+
+int fail(sph_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(c, e_ == hipErrorOutOfMemory ? SPH_E_NOMEM : SPH_E_HIP, "%s failed: %s", \
+                        #expr, hipGetErrorString(e_));                                           \
+    } while (0)
+
+#define CHECK_LAUNCH(c) HIP_TRY(c, hipGetLastError())
+
+inline int blocksFor(long long n) { return (int)((n + kBlock - 1) / kBlock); }
+
+template <class T>
+int devAlloc(sph_ctx* c, T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    HIP_TRY(c, hipMalloc((void**)p, count * sizeof(T)));
+    return SPH_OK;
+}
+
+template <class T>
+void devFree(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+void freeParticles(sph_ctx* c) {
+    for (int k = 0; k < 2; k++) {
+        devFree(c->set[k].posM); devFree(c->set[k].velV); devFree(c->set[k].acc);
+        devFree(c->set[k].rhoP); devFree(c->set[k].rho0); devFree(c->set[k].origId);
+        devFree(c->keys[k]); devFree(c->vals[k]);
+    }
+    devFree(c->color); devFree(c->phaseOfId); devFree(c->sid); devFree(c->perm2);
+    devFree(c->blockHist); devFree(c->aosStage);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    c->pinned = nullptr; c->pinnedBytes = 0;
+    c->capacity = 0; c->n = 0; c->blockHistElems = 0;
+}
+
+void freeGrid(sph_ctx* c) {
+    devFree(c->cellStart); devFree(c->cellEnd);
+    c->cellCapacity = 0; c->cells = 0;
+}
+
+int ensurePinned(sph_ctx* c, size_t bytes) {
+    if (bytes <= c->pinnedBytes) return SPH_OK;
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    c->pinned = nullptr; c->pinnedBytes = 0;
+    HIP_TRY(c, hipHostMalloc(&c->pinned, bytes, hipHostMallocDefault));
+    c->pinnedBytes = bytes;
+    return SPH_OK;
+}
+
+// O4: constants derived once on the host in fp32 (compute:20-21, 150-151, 214-216, 262, 269).
+void deriveParams(sph_ctx* c) {
+    const sph_params& q = c->prm;
+    DevParams& d = c->dp;
+    const float PI = 3.14159265359f;
+    d.n = c->n;
+    d.dt = q.deltaTime;
+    d.soundSpeed = q.soundSpeed; d.gamma = q.gamma; d.h = q.smoothingRadius; d.gravity = q.gravity;
+    d.sigma = q.surfaceTensionCoefficient; d.stThreshold = q.surfaceTensionThreshold;
+    d.xsphEps = q.xsphEpsilon; d.collisionDamping = q.particleCollisionDamping;
+    d.obstacleRadius = q.obstacleRadius;
+    for (int k = 0; k < 3; k++) {
+        d.obstaclePos[k] = q.obstaclePos[k];
+        d.boundsCenter[k] = q.boundsCenter[k];
+        d.boundsSize[k] = q.boundsSize[k];
+        d.minBound[k] = q.minBound[k];
+    }
+    d.rx = q.gridResolutionX; d.ry = q.gridResolutionY; d.rz = q.gridResolutionZ;
+    d.cap = q.maxParticlesPerCell;
+    d.cellSize = q.cellSize;
+    for (int k = 0; k < 12; k++) { d.M[k] = q.boundaryMatrix[k]; d.Minv[k] = q.boundaryInvMatrix[k]; }
+    const float* he = q.boundaryHalfExtents;
+    d.obb = sqrtf((he[0] * he[0] + he[1] * he[1]) + he[2] * he[2]) > 0.001f ? 1 : 0;
+    const float h = q.smoothingRadius;
+    d.h2 = h * h;
+    d.poly6 = 315.0f / (64.0f * PI * powf(h, 9.0f));
+    d.spikyGradFactor = -45.0f / (PI * powf(h, 6.0f));
+    d.viscLapFactor = 45.0f / (PI * powf(h, 6.0f));
+    d.lapColFactor = 1890.0f / (64.0f * PI * powf(h, 9.0f));
+}
+
+int checkReady(sph_ctx* c, bool needGrid) {
+    if (!c) return SPH_E_INVALID;
+    if (c->n <= 0) return fail(c, SPH_E_STATE, "no particles allocated");
+    if (!c->haveParams) return fail(c, SPH_E_STATE, "sph_set_params not called");
+    if (c->cells <= 0) return fail(c, SPH_E_STATE, "sph_resize_grid not called");
+    if (c->dp.rx != c->rx || c->dp.ry != c->ry || c->dp.rz != c->rz || c->dp.cap != c->cap)
+        return fail(c, SPH_E_STATE, "params grid (%d,%d,%d,cap %d) != allocated grid (%d,%d,%d,cap %d)", c->dp.rx,
+                    c->dp.ry, c->dp.rz, c->dp.cap, c->rx, c->ry, c->rz, c->cap);
+    if (c->dp.n != c->n) return fail(c, SPH_E_STATE, "params particleCount %d != allocated %d", c->dp.n, c->n);
+    if (!(c->dp.cellSize > 0.0f)) return fail(c, SPH_E_INVALID, "cellSize must be > 0");
+    if (needGrid && !c->gridValid) return fail(c, SPH_E_STATE, "grid not built (dispatch CS_BuildGrid first)");
+    return SPH_OK;
+}
+
+int applyPhaseTable(sph_ctx* c) {
+    if (!c->staticDirty) return SPH_OK;
+    if (c->phaseTable.empty() || !c->havePhaseIds) { c->staticDirty = false; return SPH_OK; }
+    hipLaunchKernelGGL(k_apply_phase_table, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->n,
+                       StateSet{c->set[c->cur].posM, c->set[c->velCur].velV, c->set[c->cur].acc,
+                                c->set[c->cur].rhoP, c->set[c->cur].rho0, c->set[c->cur].origId},
+                       c->color, c->phaseOfId, c->phaseTableDev);
+    CHECK_LAUNCH(c);
+    c->staticDirty = false;
+    return SPH_OK;
+}
+
+StateSet curSet(sph_ctx* c) {
+    StateSet s = c->set[c->cur];
+    s.velV = c->set[c->velCur].velV;
+    return s;
+}
+
+// CS_ClearGrid (compute:104-111): a bin is a [start,end) range here, so clearing = zero ranges.
+int clearGrid(sph_ctx* c) {
+    HIP_TRY(c, hipMemsetAsync(c->cellStart, 0, sizeof(int) * (size_t)c->cells, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->cellEnd, 0, sizeof(int) * (size_t)c->cells, c->stream));
+    c->gridValid = false;
+    return SPH_OK;
+}
+
+// CS_BuildGrid (compute:117-136): hash -> stable radix sort by cell -> ranges -> id order inside
+// each cell -> physical reorder of the state into (cell, id) order.
+int buildGrid(sph_ctx* c) {
+    const int n = c->n;
+    const int nb = blocksFor(n);
+    int rc = clearGrid(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->counters + SPH_CTR_BIN_OVERFLOW, 0, 2 * sizeof(int), c->stream));
+    StateSet src = curSet(c);
+    hipLaunchKernelGGL(k_hash, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, src.posM, c->keys[0], c->counters);
+    CHECK_LAUNCH(c);
+
+    int bits = 1;
+    while ((1ll << bits) < c->cells) bits++;
+    const int passes = (bits + 7) / 8;
+    const int sortBlocks = (n + kSortTile - 1) / kSortTile;
+    int in = 0;
+    for (int p = 0; p < passes; p++) {
+        const int shift = 8 * p;
+        hipLaunchKernelGGL(k_sort_hist, dim3(sortBlocks), dim3(kBlock), 0, c->stream, c->keys[in], n, shift,
+                           c->blockHist, sortBlocks);
+        hipLaunchKernelGGL(k_sort_scan_rows, dim3(kRadix), dim3(kBlock), 0, c->stream, c->blockHist, sortBlocks,
+                           c->digitTotal);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(sortBlocks), dim3(kBlock), 0, c->stream, c->keys[in],
+                           p == 0 ? (const uint32_t*)nullptr : c->vals[in], c->keys[1 - in], c->vals[1 - in], n,
+                           shift, c->blockHist, sortBlocks, c->digitTotal);
+        CHECK_LAUNCH(c);
+        in = 1 - in;
+    }
+    c->sortedKeys = c->keys[in];
+    uint32_t* perm = c->vals[in];
+    hipLaunchKernelGGL(k_cell_ranges, dim3(nb), dim3(kBlock), 0, c->stream, c->sortedKeys, n, c->cellStart,
+                       c->cellEnd);
+    hipLaunchKernelGGL(k_gather_ids, dim3(nb), dim3(kBlock), 0, c->stream, perm, src.origId, n, c->sid);
+    StateSet dst = c->set[1 - c->cur];
+    // velocities of the new order go to the set that does NOT hold the current ones
+    dst.velV = c->set[1 - c->velCur].velV;
+    hipLaunchKernelGGL(k_rank_in_cell, dim3(nb), dim3(kBlock), 0, c->stream, c->sortedKeys, perm, c->sid, n, c->cap,
+                       c->cellStart, c->cellEnd, c->perm2, dst.origId, c->counters);
+    hipLaunchKernelGGL(k_permute_state, dim3(nb), dim3(kBlock), 0, c->stream, n, c->perm2, src, dst);
+    CHECK_LAUNCH(c);
+    c->cur = 1 - c->cur;
+    c->velCur = 1 - c->velCur;
+    c->gridValid = true;
+    return SPH_OK;
+}
+
+int dispatchKernel(sph_ctx* c, int id) {
+    const int n = c->n;
+    const int nb = blocksFor(n);
+    StateSet s = curSet(c);
+    switch (id) {
+        case SPH_K_CLEAR:
+            hipLaunchKernelGGL(k_clear, dim3(nb), dim3(kBlock), 0, c->stream, n, s.acc, s.rhoP, s.rho0);
+            break;
+        case SPH_K_CLEAR_GRID:
+            return clearGrid(c);
+        case SPH_K_BUILD_GRID:
+            return buildGrid(c);
+        case SPH_K_DENSITY_PRESSURE:
+            hipLaunchKernelGGL(k_density_pressure, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.rho0, s.rhoP,
+                               c->cellStart, c->cellEnd);
+            break;
+        case SPH_K_FORCE_XSPH: {
+            float4* velOut = c->set[1 - c->velCur].velV;
+            hipLaunchKernelGGL(k_force_xsph, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, s.rhoP, s.acc,
+                               velOut, c->cellStart, c->cellEnd);
+            c->velCur = 1 - c->velCur;
+            break;
+        }
+        case SPH_K_VV_HALF_STEP:
+            hipLaunchKernelGGL(k_half_step, dim3(nb), dim3(kBlock), 0, c->stream, n, c->dp.dt, s.posM, s.velV, s.acc);
+            break;
+        case SPH_K_VV_FULL_STEP:
+            hipLaunchKernelGGL(k_full_step, dim3(nb), dim3(kBlock), 0, c->stream, n, c->dp.dt, s.velV, s.acc);
+            break;
+        case SPH_K_BOUND_OBS:
+            hipLaunchKernelGGL(k_bound_obs, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, c->counters);
+            break;
+        case SPH_K_VELOCITY_DAMPING:
+            hipLaunchKernelGGL(k_velocity_damping, dim3(nb), dim3(kBlock), 0, c->stream, n, s.velV);
+            break;
+        default:
+            return fail(c, SPH_E_INVALID, "bad kernel id %d", id);
+    }
+    CHECK_LAUNCH(c);
+    return SPH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sph_version(void) { return "libsph_hip 0.1 (gfx950, hand-written HIP)"; }
+
+const char* sph_last_error(const sph_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+int sph_create(sph_ctx** out, int device_id) {
+    if (!out) return SPH_E_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return SPH_E_NO_DEVICE;
+    if (device_id < 0 || device_id >= count) return SPH_E_NO_DEVICE;
+    sph_ctx* c = new (std::nothrow) sph_ctx();
+    if (!c) return SPH_E_NOMEM;
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return SPH_E_HIP;
+    }
+    for (int k = 0; k < kNumEvents; k++) (void)hipEventCreate(&c->ev[k]);
+    if (hipMalloc((void**)&c->counters, SPH_CTR_COUNT * sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&c->digitTotal, kRadix * sizeof(uint32_t)) != hipSuccess ||
+        hipMemsetAsync(c->counters, 0, SPH_CTR_COUNT * sizeof(int), c->stream) != hipSuccess) {
+        sph_destroy(c);
+        return SPH_E_NOMEM;
+    }
+    *out = c;
+    return SPH_OK;
+}
+
+int sph_destroy(sph_ctx* c) {
+    if (!c) return SPH_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    freeParticles(c);
+    freeGrid(c);
+    devFree(c->counters);
+    devFree(c->digitTotal);
+    devFree(c->phaseTableDev);
+    for (int k = 0; k < kNumEvents; k++)
+        if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SPH_OK;
+}
+
+int sph_alloc_particles(sph_ctx* c, int n) {
+    if (!c) return SPH_E_INVALID;
+    if (n <= 0) return fail(c, SPH_E_INVALID, "particle count must be > 0 (got %d)", n);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n > c->capacity) {
+        freeParticles(c);
+        int rc = 0;
+        for (int k = 0; k < 2 && !rc; k++) {
+            rc = devAlloc(c, &c->set[k].posM, n);
+            if (!rc) rc = devAlloc(c, &c->set[k].velV, n);
+            if (!rc) rc = devAlloc(c, &c->set[k].acc, n);
+            if (!rc) rc = devAlloc(c, &c->set[k].rhoP, n);
+            if (!rc) rc = devAlloc(c, &c->set[k].rho0, n);
+            if (!rc) rc = devAlloc(c, &c->set[k].origId, n);
+            if (!rc) rc = devAlloc(c, &c->keys[k], n);
+            if (!rc) rc = devAlloc(c, &c->vals[k], n);
+        }
+        if (!rc) rc = devAlloc(c, &c->color, n);
+        if (!rc) rc = devAlloc(c, &c->phaseOfId, n);
+        if (!rc) rc = devAlloc(c, &c->sid, n);
+        if (!rc) rc = devAlloc(c, &c->perm2, n);
+        if (!rc) rc = devAlloc(c, &c->aosStage, (size_t)n * SPH_PARTICLE_FLOATS);
+        c->blockHistElems = (size_t)kRadix * ((n + kSortTile - 1) / kSortTile);
+        if (!rc) rc = devAlloc(c, &c->blockHist, c->blockHistElems);
+        if (rc) { freeParticles(c); return rc; }
+        c->capacity = n;
+    }
+    c->n = n;
+    c->cur = 0; c->velCur = 0;
+    c->gridValid = false;
+    c->havePhaseIds = false;
+    c->dp.n = c->haveParams ? c->prm.particleCount : 0;
+    // a fresh ComputeBuffer is zero-filled; give ids so download before upload is well defined
+    HIP_TRY(c, hipMemsetAsync(c->aosStage, 0, (size_t)n * SPH_PARTICLE_BYTES, c->stream));
+    hipLaunchKernelGGL(k_import_aos, dim3(blocksFor(n)), dim3(kBlock), 0, c->stream, n, c->aosStage, c->set[0], c->color);
+    CHECK_LAUNCH(c);
+    return SPH_OK;
+}
+
+int sph_upload_particles(sph_ctx* c, const void* aos72, int n) {
+    if (!c) return SPH_E_INVALID;
+    if (!aos72) return fail(c, SPH_E_INVALID, "null particle array");
+    if (n != c->n || n <= 0) return fail(c, SPH_E_INVALID, "upload count %d != allocated %d", n, c->n);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)n * SPH_PARTICLE_BYTES;
+    int rc = ensurePinned(c, bytes);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // previous use of the staging buffers
+    memcpy(c->pinned, aos72, bytes);
+    HIP_TRY(c, hipMemcpyAsync(c->aosStage, c->pinned, bytes, hipMemcpyHostToDevice, c->stream));
+    c->cur = 0; c->velCur = 0;
+    hipLaunchKernelGGL(k_import_aos, dim3(blocksFor(n)), dim3(kBlock), 0, c->stream, n, c->aosStage, c->set[0], c->color);
+    CHECK_LAUNCH(c);
+    c->gridValid = false;
+    c->staticDirty = true;   // SPH.cs:284-298 would overwrite the static fields on the next Update
+    return SPH_OK;
+}
+
+int sph_download_particles(sph_ctx* c, void* aos72, int n) {
+    if (!c) return SPH_E_INVALID;
+    if (!aos72) return fail(c, SPH_E_INVALID, "null particle array");
+    if (n != c->n || n <= 0) return fail(c, SPH_E_INVALID, "download count %d != allocated %d", n, c->n);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)n * SPH_PARTICLE_BYTES;
+    int rc = ensurePinned(c, bytes);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_export_aos, dim3(blocksFor(n)), dim3(kBlock), 0, c->stream, n, c->aosStage, curSet(c), c->color);
+    CHECK_LAUNCH(c);
+    HIP_TRY(c, hipMemcpyAsync(c->pinned, c->aosStage, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memcpy(aos72, c->pinned, bytes);
+    return SPH_OK;
+}
+
+int sph_resize_grid(sph_ctx* c, int rx, int ry, int rz, int max_per_cell) {
+    if (!c) return SPH_E_INVALID;
+    if (rx <= 0 || ry <= 0 || rz <= 0 || max_per_cell <= 0)
+        return fail(c, SPH_E_INVALID, "bad grid %d x %d x %d cap %d", rx, ry, rz, max_per_cell);
+    const long long cells = (long long)rx * ry * rz;
+    if (cells > 0x7FFFFFFFll) return fail(c, SPH_E_INVALID, "grid has %lld cells (> 2^31-1)", cells);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (cells > c->cellCapacity) {
+        // grow-only, with headroom: a rocking boundary cube changes the AABB every frame
+        // (SPH.cs:176-185 -> 339-345 reallocates each time; here that is a no-op almost always)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        freeGrid(c);
+        long long want = cells + cells / 4;
+        if (want > 0x7FFFFFFFll) want = 0x7FFFFFFFll;
+        int rc = devAlloc(c, &c->cellStart, (size_t)want);
+        if (!rc) rc = devAlloc(c, &c->cellEnd, (size_t)want);
+        if (rc) { freeGrid(c); return rc; }
+        c->cellCapacity = want;
+    }
+    c->rx = rx; c->ry = ry; c->rz = rz; c->cap = max_per_cell; c->cells = cells;
+    c->gridValid = false;   // fresh GridCounts/GridIndices buffers (SPH.cs:344-345)
+    return SPH_OK;
+}
+
+int sph_set_params(sph_ctx* c, const sph_params* p) {
+    if (!c) return SPH_E_INVALID;
+    if (!p) return fail(c, SPH_E_INVALID, "null params");
+    if (p->struct_size != sizeof(sph_params))
+        return fail(c, SPH_E_INVALID, "sph_params.struct_size %u != %zu", p->struct_size, sizeof(sph_params));
+    c->prm = *p;
+    c->haveParams = true;
+    deriveParams(c);
+    c->dp.n = p->particleCount;
+    return SPH_OK;
+}
+
+int sph_set_delta_time(sph_ctx* c, float dt) {
+    if (!c) return SPH_E_INVALID;
+    c->prm.deltaTime = dt;
+    c->dp.dt = dt;
+    return SPH_OK;
+}
+
+int sph_set_phase_table(sph_ctx* c, const sph_phase* table, int n_phases) {
+    if (!c) return SPH_E_INVALID;
+    if (!table || n_phases <= 0 || n_phases > 256) return fail(c, SPH_E_INVALID, "bad phase table (n=%d)", n_phases);
+    if ((int)c->phaseTable.size() == n_phases && memcmp(c->phaseTable.data(), table, sizeof(sph_phase) * n_phases) == 0)
+        return SPH_OK;   // unchanged since last frame: nothing to re-apply
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if ((int)c->phaseTable.size() != n_phases) {
+        devFree(c->phaseTableDev);
+        int rc = devAlloc(c, &c->phaseTableDev, (size_t)n_phases);
+        if (rc) return rc;
+    }
+    c->phaseTable.assign(table, table + n_phases);
+    HIP_TRY(c, hipMemcpy(c->phaseTableDev, table, sizeof(sph_phase) * n_phases, hipMemcpyHostToDevice));
+    c->staticDirty = true;
+    return SPH_OK;
+}
+
+int sph_set_phase_ids(sph_ctx* c, const uint8_t* ids, int n) {
+    if (!c) return SPH_E_INVALID;
+    if (!ids || n != c->n || n <= 0) return fail(c, SPH_E_INVALID, "phase id count %d != allocated %d", n, c->n);
+    const int np = (int)c->phaseTable.size();
+    if (np == 0) return fail(c, SPH_E_STATE, "sph_set_phase_table first");
+    for (int i = 0; i < n; i++)
+        if (ids[i] >= np) return fail(c, SPH_E_INVALID, "phase id %d of particle %d out of range (%d phases)", ids[i], i, np);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(c->phaseOfId, ids, (size_t)n, hipMemcpyHostToDevice));
+    c->havePhaseIds = true;
+    c->staticDirty = true;
+    return SPH_OK;
+}
+
+int sph_apply_phase_table(sph_ctx* c) {
+    if (!c) return SPH_E_INVALID;
+    if (c->n <= 0) return fail(c, SPH_E_STATE, "no particles allocated");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return applyPhaseTable(c);
+}
+
+int sph_dispatch(sph_ctx* c, int kernel_id, int count) {
+    if (!c) return SPH_E_INVALID;
+    if (kernel_id < 0 || kernel_id >= SPH_K_COUNT) return fail(c, SPH_E_INVALID, "bad kernel id %d", kernel_id);
+    const bool usesGrid = kernel_id == SPH_K_DENSITY_PRESSURE || kernel_id == SPH_K_FORCE_XSPH;
+    int rc = checkReady(c, usesGrid);
+    if (rc) return rc;
+    const long long expect = kernel_id == SPH_K_CLEAR_GRID ? c->cells : c->n;
+    if (count != expect)
+        return fail(c, SPH_E_INVALID, "dispatch count %d != %lld (SPH.cs always dispatches the full buffer)", count, expect);
+    HIP_TRY(c, hipSetDevice(c->device));
+    return dispatchKernel(c, kernel_id);
+}
+
+int sph_step_frame(sph_ctx* c, int sub_steps, float time_step) {
+    if (!c) return SPH_E_INVALID;
+    if (sub_steps < 1) return fail(c, SPH_E_INVALID, "subSteps must be >= 1");
+    int rc = checkReady(c, false);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if ((rc = applyPhaseTable(c))) return rc;                               // SPH.cs:198
+    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    if ((rc = dispatchKernel(c, SPH_K_CLEAR_GRID))) return rc;               // SPH.cs:201
+    if ((rc = dispatchKernel(c, SPH_K_BUILD_GRID))) return rc;               // SPH.cs:204
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    sph_set_delta_time(c, time_step / (float)sub_steps);                    // SPH.cs:207-208
+    for (int s = 0; s < sub_steps; s++) {                                   // SPH.cs:210-219
+        const bool last = s == sub_steps - 1;
+        if ((rc = dispatchKernel(c, SPH_K_VV_HALF_STEP))) return rc;
+        if (last) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+        if ((rc = dispatchKernel(c, SPH_K_CLEAR))) return rc;
+        if ((rc = dispatchKernel(c, SPH_K_DENSITY_PRESSURE))) return rc;
+        if (last) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+        if ((rc = dispatchKernel(c, SPH_K_FORCE_XSPH))) return rc;
+        if (last) HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
+        if ((rc = dispatchKernel(c, SPH_K_VV_FULL_STEP))) return rc;
+        if (last) HIP_TRY(c, hipEventRecord(c->ev[5], c->stream));
+        if ((rc = dispatchKernel(c, SPH_K_BOUND_OBS))) return rc;
+        if (last) HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
+    }
+    if ((rc = dispatchKernel(c, SPH_K_VELOCITY_DAMPING))) return rc;         // SPH.cs:222
+    HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
+    c->timingsValid = true;
+    return SPH_OK;
+}
+
+int sph_synchronize(sph_ctx* c) {
+    if (!c) return SPH_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_reset_counter(sph_ctx* c, int which) {
+    if (!c) return SPH_E_INVALID;
+    if (which < 0 || which >= SPH_CTR_COUNT) return fail(c, SPH_E_INVALID, "bad counter %d", which);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemsetAsync(c->counters + which, 0, sizeof(int), c->stream));
+    return SPH_OK;
+}
+
+int sph_read_counter(sph_ctx* c, int which, int* value) {
+    if (!c) return SPH_E_INVALID;
+    if (which < 0 || which >= SPH_CTR_COUNT || !value) return fail(c, SPH_E_INVALID, "bad counter %d", which);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(value, c->counters + which, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_download_grid(sph_ctx* c, int32_t* cell_start, int32_t* cell_end, int32_t* sorted_ids,
+                      uint32_t* cell_of_particle) {
+    if (!c) return SPH_E_INVALID;
+    if (!c->gridValid) return fail(c, SPH_E_STATE, "grid not built");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t cb = sizeof(int) * (size_t)c->cells, nb = sizeof(int) * (size_t)c->n;
+    if (cell_start) HIP_TRY(c, hipMemcpyAsync(cell_start, c->cellStart, cb, hipMemcpyDeviceToHost, c->stream));
+    if (cell_end) HIP_TRY(c, hipMemcpyAsync(cell_end, c->cellEnd, cb, hipMemcpyDeviceToHost, c->stream));
+    if (sorted_ids)
+        HIP_TRY(c, hipMemcpyAsync(sorted_ids, c->set[c->cur].origId, nb, hipMemcpyDeviceToHost, c->stream));
+    if (cell_of_particle) {
+        hipLaunchKernelGGL(k_scatter_by_id, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->n, c->sortedKeys,
+                           c->set[c->cur].origId, c->sid);
+        CHECK_LAUNCH(c);
+        HIP_TRY(c, hipMemcpyAsync(cell_of_particle, c->sid, nb, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_download_neighbors(sph_ctx* c, int32_t* counts, int32_t* lists, int max_neighbors) {
+    if (!c) return SPH_E_INVALID;
+    if (!counts || max_neighbors < 0) return fail(c, SPH_E_INVALID, "bad neighbour export arguments");
+    int rc = checkReady(c, true);
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int *dCounts = nullptr, *dLists = nullptr;
+    const size_t lb = sizeof(int) * (size_t)c->n * (size_t)max_neighbors;
+    HIP_TRY(c, hipMalloc((void**)&dCounts, sizeof(int) * (size_t)c->n));
+    if (lists && lb) {
+        hipError_t e = hipMalloc((void**)&dLists, lb);
+        if (e != hipSuccess) { (void)hipFree(dCounts); return fail(c, SPH_E_NOMEM, "neighbour list alloc failed"); }
+        (void)hipMemsetAsync(dLists, 0xFF, lb, c->stream);   // unused tail entries read back as -1
+    }
+    StateSet s = curSet(c);
+    hipLaunchKernelGGL(k_export_neighbors, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.origId,
+                       c->cellStart, c->cellEnd, dCounts, dLists, max_neighbors);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(counts, dCounts, sizeof(int) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && dLists) e = hipMemcpyAsync(lists, dLists, lb, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dCounts);
+    if (dLists) (void)hipFree(dLists);
+    if (e != hipSuccess) return fail(c, SPH_E_HIP, "neighbour export failed: %s", hipGetErrorString(e));
+    return SPH_OK;
+}
+
+int sph_get_timings(sph_ctx* c, sph_timings* out) {
+    if (!c) return SPH_E_INVALID;
+    if (!out) return fail(c, SPH_E_INVALID, "null timings");
+    if (!c->timingsValid) return fail(c, SPH_E_STATE, "no sph_step_frame has run");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventSynchronize(c->ev[7]));
+    float t[8] = {0};
+    for (int k = 0; k < 7; k++) HIP_TRY(c, hipEventElapsedTime(&t[k], c->ev[k], c->ev[k + 1]));
+    HIP_TRY(c, hipEventElapsedTime(&t[7], c->ev[0], c->ev[7]));
+    out->build_grid_ms = t[0];
+    out->half_step_ms = t[1];
+    out->density_ms = t[2];     // includes CS_Clear
+    out->force_ms = t[3];
+    out->full_step_ms = t[4];
+    out->bound_obs_ms = t[5];
+    out->damping_ms = t[6];
+    out->frame_ms = t[7];
+    return SPH_OK;
+}
+
+int sph_device_pointer(sph_ctx* c, const char* name, void** ptr, uint64_t* bytes) {
+    if (!c) return SPH_E_INVALID;
+    if (!name || !ptr) return fail(c, SPH_E_INVALID, "null argument");
+    StateSet s = curSet(c);
+    const uint64_t n = (uint64_t)c->n;
+    uint64_t b = 0;
+    void* p = nullptr;
+    if (!strcmp(name, "posM")) { p = s.posM; b = n * 16; }
+    else if (!strcmp(name, "velV")) { p = s.velV; b = n * 16; }
+    else if (!strcmp(name, "acc")) { p = s.acc; b = n * 16; }
+    else if (!strcmp(name, "rhoP")) { p = s.rhoP; b = n * 8; }
+    else if (!strcmp(name, "rho0")) { p = s.rho0; b = n * 4; }
+    else if (!strcmp(name, "origId")) { p = s.origId; b = n * 4; }
+    else return fail(c, SPH_E_INVALID, "unknown buffer '%s'", name);
+    *ptr = p;
+    if (bytes) *bytes = b;
+    return SPH_OK;
+}
+
+int sph_get_stream(sph_ctx* c, void** stream) {
+    if (!c || !stream) return SPH_E_INVALID;
+    *stream = (void*)c->stream;
+    return SPH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,349 @@
+// physics_kernels.h -- per-particle SPH stages on the slot-ordered SoA state (gfx950).
+// Each kernel states the reference kernel it stands in for (Assets/SPHCompute.compute).
+#pragma once
+#include "grid_kernels.h"
+
+namespace sph {
+
+// dot(a,a) exactly as the oracle evaluates it (rule O5): (x*x + y*y) + z*z, every operation
+// rounded, no FMA -- the in-range test rSq < h2 decides neighbour-list membership and has to
+// agree bit for bit.  The TU is built with -ffp-contract=off; the pragma pins it locally too.
+__device__ __forceinline__ float dist2_exact(float rx, float ry, float rz) {
+#pragma clang fp contract(off)
+    float a = rx * rx;
+    float b = ry * ry;
+    float c = rz * rz;
+    return (a + b) + c;
+}
+
+// Calls f(j) for every candidate slot j of the particle in slot `self` at position (px,py,pz),
+// in the reference's visiting order: z, y, x cells around the UNCLAMPED own cell (rule O7),
+// then ascending id inside a cell, at most `cap` entries per cell (rule O2); skips j == self
+// (compute:158-173 / 229-244).
+template <class F>
+__device__ __forceinline__ void for_each_candidate(const DevParams& P, const int* __restrict__ cellStart,
+                                                   const int* __restrict__ cellEnd, int self, float px, float py,
+                                                   float pz, F&& f) {
+    const int3 c = cell_unclamped(P, px, py, pz);
+    for (int z = c.z - 1; z <= c.z + 1; z++) {
+        if (z < 0 || z >= P.rz) continue;
+        for (int y = c.y - 1; y <= c.y + 1; y++) {
+            if (y < 0 || y >= P.ry) continue;
+            for (int x = c.x - 1; x <= c.x + 1; x++) {
+                if (x < 0 || x >= P.rx) continue;
+                const int ci = x + y * P.rx + z * P.rx * P.ry;
+                const int a = cellStart[ci];
+                const int e = min(cellEnd[ci], a + P.cap);
+                for (int j = a; j < e; j++) {
+                    if (j == self) continue;
+                    f(j);
+                }
+            }
+        }
+    }
+}
+
+// CS_Clear (compute:87-98)
+__global__ __launch_bounds__(kBlock) void k_clear(int n, float4* __restrict__ acc, float2* __restrict__ rhoP,
+                                                  const float* __restrict__ rho0) {
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    rhoP[s] = make_float2(rho0[s], 0.f);
+}
+
+// CS_DensityPressure (compute:142-193)
+__global__ __launch_bounds__(kBlock) void k_density_pressure(DevParams P, const float4* __restrict__ posM,
+                                                             const float* __restrict__ rho0,
+                                                             float2* __restrict__ rhoP,
+                                                             const int* __restrict__ cellStart,
+                                                             const int* __restrict__ cellEnd) {
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= P.n) return;
+    const float4 p = posM[s];
+    float density = 0.0f;
+    for_each_candidate(P, cellStart, cellEnd, s, p.x, p.y, p.z, [&](int j) {
+        const float4 q = posM[j];
+        const float rx = p.x - q.x, ry = p.y - q.y, rz = p.z - q.z;
+        const float rSq = dist2_exact(rx, ry, rz);
+        if (rSq < P.h2) {
+            const float diff = P.h2 - rSq;
+            density += q.w * P.poly6 * diff * diff * diff;                 // compute:180
+        }
+    });
+    const float r0 = rho0[s];
+    density = fmaxf(density, r0);                                          // compute:186
+    const float localB = r0 * (P.soundSpeed * P.soundSpeed) / P.gamma;     // compute:189
+    const float pressure = localB * (powf(density / r0, P.gamma) - 1.0f);  // compute:190
+    rhoP[s] = make_float2(density, pressure);
+}
+
+// CS_ForceXSPH (compute:199-303).  Neighbour velocities come from velIn, the own corrected
+// velocity goes to velOut (a different buffer): the Jacobi reading of the reference's in-place
+// update (ORACLE rule O3).
+__global__ __launch_bounds__(kBlock) void k_force_xsph(DevParams P, const float4* __restrict__ posM,
+                                                       const float4* __restrict__ velIn,
+                                                       const float2* __restrict__ rhoP, float4* __restrict__ acc,
+                                                       float4* __restrict__ velOut,
+                                                       const int* __restrict__ cellStart,
+                                                       const int* __restrict__ cellEnd) {
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= P.n) return;
+    const float4 p = posM[s];
+    const float4 v = velIn[s];
+    const float2 dp = rhoP[s];
+    const float densitySelf = dp.x;
+    if (densitySelf < 1e-6f) {                                             // compute:207-211
+        velOut[s] = v;
+        return;
+    }
+    float fx = 0.0f, fy = P.gravity * densitySelf, fz = 0.0f;              // compute:219
+    float cgx = 0.f, cgy = 0.f, cgz = 0.f, colorLaplacian = 0.f;
+    float vcx = 0.f, vcy = 0.f, vcz = 0.f, normFactor = 0.f;
+    const float selfTerm = dp.y / (densitySelf * densitySelf);
+    for_each_candidate(P, cellStart, cellEnd, s, p.x, p.y, p.z, [&](int j) {
+        const float4 q = posM[j];
+        const float rx = p.x - q.x, ry = p.y - q.y, rz = p.z - q.z;
+        const float rSq = dist2_exact(rx, ry, rz);
+        if (rSq < P.h2) {
+            const float4 u = velIn[j];
+            const float2 o = rhoP[j];
+            const float dist = sqrtf(rSq) + 1e-6f;                         // compute:250
+            const float dirx = rx / dist, diry = ry / dist, dirz = rz / dist;
+            const float diff = P.h2 - rSq;
+            const float pressureTerm = selfTerm + (o.y / (o.x * o.x));     // compute:255-256
+            const float gs = P.spikyGradFactor * diff * diff;
+            const float gwx = gs * dirx, gwy = gs * diry, gwz = gs * dirz; // compute:257
+            const float pf = -q.w * pressureTerm;
+            fx += pf * gwx; fy += pf * gwy; fz += pf * gwz;                // compute:258
+            const float dvx = u.x - v.x, dvy = u.y - v.y, dvz = u.z - v.z; // compute:261
+            const float lapWv = P.viscLapFactor * (P.h - dist);            // compute:263
+            const float vm = (0.5f * (v.w + u.w)) * q.w;                   // compute:264-265
+            fx += vm * dvx / o.x * lapWv;
+            fy += vm * dvy / o.x * lapWv;
+            fz += vm * dvz / o.x * lapWv;
+            cgx += q.w * gwx / o.x;                                        // compute:268
+            cgy += q.w * gwy / o.x;
+            cgz += q.w * gwz / o.x;
+            const float lapW = -P.lapColFactor * (P.h2 - rSq) * (P.h2 - 5.0f * rSq);  // compute:269
+            colorLaplacian += q.w * lapW / o.x;                            // compute:270
+            const float W = P.poly6 * diff * diff * diff;                  // compute:274
+            const float mr = q.w / (0.5f * (densitySelf + o.x));           // compute:275
+            vcx += dvx * W * mr; vcy += dvy * W * mr; vcz += dvz * W * mr; // compute:276
+            normFactor += W * mr;                                          // compute:277
+        }
+    });
+    const float gradMag = sqrtf((cgx * cgx + cgy * cgy) + cgz * cgz);      // compute:285
+    if (gradMag > P.stThreshold) {
+        const float curvature = colorLaplacian / (gradMag + 1e-6f);
+        const float st = -P.sigma * curvature;
+        fx += st * (cgx / gradMag); fy += st * (cgy / gradMag); fz += st * (cgz / gradMag);
+    }
+    acc[s] = make_float4(fx / densitySelf, fy / densitySelf, fz / densitySelf, 0.f);   // compute:293
+    float4 vo = v;
+    if (normFactor > 1e-6f) {                                              // compute:296-300
+        const float sc = P.xsphEps / normFactor;
+        vo.x += vcx * sc; vo.y += vcy * sc; vo.z += vcz * sc;
+    }
+    velOut[s] = vo;
+}
+
+// CS_VvHalfStep (compute:309-319)
+__global__ __launch_bounds__(kBlock) void k_half_step(int n, float dt, float4* __restrict__ posM,
+                                                      float4* __restrict__ velV, const float4* __restrict__ acc) {
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    float4 p = posM[s], v = velV[s];
+    const float4 a = acc[s];
+    const float hdt = 0.5f * dt;
+    v.x += hdt * a.x; v.y += hdt * a.y; v.z += hdt * a.z;
+    p.x += v.x * dt; p.y += v.y * dt; p.z += v.z * dt;
+    velV[s] = v;
+    posM[s] = p;
+}
+
+// CS_VvFullStep (compute:325-334)
+__global__ __launch_bounds__(kBlock) void k_full_step(int n, float dt, float4* __restrict__ velV,
+                                                      const float4* __restrict__ acc) {
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    float4 v = velV[s];
+    const float4 a = acc[s];
+    const float hdt = 0.5f * dt;
+    v.x += hdt * a.x; v.y += hdt * a.y; v.z += hdt * a.z;
+    velV[s] = v;
+}
+
+__device__ __forceinline__ float dot3f(float ax, float ay, float az, float bx, float by, float bz) {
+    return (ax * bx + ay * by) + az * bz;
+}
+
+// CS_BoundObs (compute:340-486).  The per-collision InterlockedAdd (compute:418) becomes one
+// wave ballot + popcount and a single atomic per wave.
+__global__ __launch_bounds__(kBlock) void k_bound_obs(DevParams P, float4* __restrict__ posM,
+                                                      float4* __restrict__ velV, int* __restrict__ counters) {
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    bool collided = false;
+    if (s < P.n) {
+        float4 p = posM[s], v = velV[s];
+        if (P.obb) {
+            float lp[3], pen[3] = {0.f, 0.f, 0.f};
+            for (int r = 0; r < 3; r++)
+                lp[r] = ((P.Minv[r * 4 + 0] * p.x + P.Minv[r * 4 + 1] * p.y) + P.Minv[r * 4 + 2] * p.z) +
+                        P.Minv[r * 4 + 3] * 1.0f;                          // compute:351
+            const float E = 0.5f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {                                  // compute:357-392
+                if (lp[k] < -E) { pen[k] = -E - lp[k]; lp[k] = -E; collided = true; }
+                else if (lp[k] > E) { pen[k] = lp[k] - E; lp[k] = E; collided = true; }
+            }
+            if (collided) {
+                float wp[3];
+                for (int r = 0; r < 3; r++)
+                    wp[r] = ((P.M[r * 4 + 0] * lp[0] + P.M[r * 4 + 1] * lp[1]) + P.M[r * 4 + 2] * lp[2]) +
+                            P.M[r * 4 + 3] * 1.0f;                         // compute:396
+                p.x = wp[0]; p.y = wp[1]; p.z = wp[2];
+                float ln[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    if (pen[k] > 0.0f) ln[k] = (lp[k] < 0.0f) ? -1.0f : 1.0f;          // compute:400-405
+                const float l = sqrtf(dot3f(ln[0], ln[1], ln[2], ln[0], ln[1], ln[2]));
+                ln[0] /= l; ln[1] /= l; ln[2] /= l;                        // compute:406
+                float wn[3];
+                for (int r = 0; r < 3; r++)
+                    wn[r] = (P.M[r * 4 + 0] * ln[0] + P.M[r * 4 + 1] * ln[1]) + P.M[r * 4 + 2] * ln[2];  // 408
+                const float wl = sqrtf(dot3f(wn[0], wn[1], wn[2], wn[0], wn[1], wn[2]));
+                wn[0] /= wl; wn[1] /= wl; wn[2] /= wl;
+                const float d = dot3f(v.x, v.y, v.z, wn[0], wn[1], wn[2]);
+                float vv[3] = {v.x, v.y, v.z};
+#pragma unroll
+                for (int k = 0; k < 3; k++) {                              // compute:411-415
+                    float vN = d * wn[k];
+                    float vT = vv[k] - vN;
+                    vv[k] = (-vN) + vT;
+                }
+                v.x = vv[0]; v.y = vv[1]; v.z = vv[2];
+            }
+        } else {                                                           // compute:423-463
+            float pp[3] = {p.x, p.y, p.z}, vv[3] = {v.x, v.y, v.z};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float halfSize = P.boundsSize[k] * 0.5f;
+                const float mn = P.boundsCenter[k] - halfSize, mx = P.boundsCenter[k] + halfSize;
+                if (pp[k] < mn) {
+                    pp[k] = mn;
+                    if (vv[k] < 0) vv[k] = -vv[k] * 0.9f;
+                } else if (pp[k] > mx) {
+                    pp[k] = mx;
+                    if (vv[k] > 0) vv[k] = -vv[k] * 0.9f;
+                }
+            }
+            p.x = pp[0]; p.y = pp[1]; p.z = pp[2];
+            v.x = vv[0]; v.y = vv[1]; v.z = vv[2];
+        }
+        if (P.obstacleRadius > 0.0f) {                                     // compute:467-483
+            const float tx = p.x - P.obstaclePos[0], ty = p.y - P.obstaclePos[1], tz = p.z - P.obstaclePos[2];
+            const float dist = sqrtf(dot3f(tx, ty, tz, tx, ty, tz));
+            if (dist < P.obstacleRadius && dist > 1e-6f) {
+                const float penetration = P.obstacleRadius - dist;
+                const float nx = tx / dist, ny = ty / dist, nz = tz / dist;
+                p.x += nx * penetration; p.y += ny * penetration; p.z += nz * penetration;
+                const float d = dot3f(v.x, v.y, v.z, nx, ny, nz);
+                v.x = (v.x - 2.0f * nx * d) * P.collisionDamping;          // reflect(v, n) * damping
+                v.y = (v.y - 2.0f * ny * d) * P.collisionDamping;
+                v.z = (v.z - 2.0f * nz * d) * P.collisionDamping;
+            } else if (dist <= 1e-6f) {
+                p.y += P.obstacleRadius + 0.01f;
+                const float d = v.y;                                       // dot(v, (0,1,0))
+                v.x = (v.x - 2.0f * 0.0f * d) * P.collisionDamping;
+                v.y = (v.y - 2.0f * 1.0f * d) * P.collisionDamping;
+                v.z = (v.z - 2.0f * 0.0f * d) * P.collisionDamping;
+            }
+        }
+        posM[s] = p;
+        velV[s] = v;
+    }
+    const unsigned long long m = __ballot(collided);
+    if (m && (threadIdx.x & 63) == 0) atomicAdd(&counters[SPH_CTR_COLLISIONS], __popcll(m));
+}
+
+// CS_VelocityDamping (compute:492-509)
+__global__ __launch_bounds__(kBlock) void k_velocity_damping(int n, float4* __restrict__ velV) {
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    float4 v = velV[s];
+    const float speed = sqrtf(dot3f(v.x, v.y, v.z, v.x, v.y, v.z));
+    const float k = (speed < 0.2f) ? 0.98f : 0.999f;
+    v.x *= k; v.y *= k; v.z *= k;
+    velV[s] = v;
+}
+
+// ---- AoS <-> SoA at the ABI (the reference's 72-byte record, id order) ------------------------------
+__global__ __launch_bounds__(kBlock) void k_import_aos(int n, const float* __restrict__ aos, StateSet st,
+                                                       float4* __restrict__ color) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float* r = aos + (size_t)i * SPH_PARTICLE_FLOATS;
+    st.posM[i] = make_float4(r[0], r[1], r[2], r[13]);
+    st.velV[i] = make_float4(r[3], r[4], r[5], r[12]);
+    st.acc[i] = make_float4(r[6], r[7], r[8], 0.f);
+    st.rhoP[i] = make_float2(r[9], r[10]);
+    st.rho0[i] = r[11];
+    st.origId[i] = (uint32_t)i;
+    color[i] = make_float4(r[14], r[15], r[16], r[17]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_export_aos(int n, float* __restrict__ aos, StateSet st,
+                                                       const float4* __restrict__ color) {
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    const uint32_t id = st.origId[s];
+    float* r = aos + (size_t)id * SPH_PARTICLE_FLOATS;
+    const float4 p = st.posM[s], v = st.velV[s], a = st.acc[s], c = color[id];
+    const float2 d = st.rhoP[s];
+    r[0] = p.x; r[1] = p.y; r[2] = p.z;
+    r[3] = v.x; r[4] = v.y; r[5] = v.z;
+    r[6] = a.x; r[7] = a.y; r[8] = a.z;
+    r[9] = d.x; r[10] = d.y; r[11] = st.rho0[s]; r[12] = v.w; r[13] = p.w;
+    r[14] = c.x; r[15] = c.y; r[16] = c.z; r[17] = c.w;
+}
+
+// SPH.UpdateParticleStaticProperties (SPH.cs:284-298) on the device: per-particle phase id ->
+// phase table row -> restDensity / viscosity / mass / colour.
+__global__ __launch_bounds__(kBlock) void k_apply_phase_table(int n, StateSet st, float4* __restrict__ color,
+                                                              const uint8_t* __restrict__ phaseOfId,
+                                                              const sph_phase* __restrict__ table) {
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    const uint32_t id = st.origId[s];
+    const sph_phase ph = table[phaseOfId[id]];
+    st.rho0[s] = ph.restDensity;
+    st.velV[s].w = ph.viscosity;
+    st.posM[s].w = ph.mass;
+    color[id] = make_float4(ph.color[0], ph.color[1], ph.color[2], ph.color[3]);
+}
+
+// Neighbour-list export (parity only): what CS_DensityPressure's loop would accept right now.
+__global__ __launch_bounds__(kBlock) void k_export_neighbors(DevParams P, const float4* __restrict__ posM,
+                                                             const uint32_t* __restrict__ origId,
+                                                             const int* __restrict__ cellStart,
+                                                             const int* __restrict__ cellEnd,
+                                                             int* __restrict__ counts, int* __restrict__ lists,
+                                                             int maxNeighbors) {
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= P.n) return;
+    const float4 p = posM[s];
+    const uint32_t id = origId[s];
+    int cnt = 0;
+    for_each_candidate(P, cellStart, cellEnd, s, p.x, p.y, p.z, [&](int j) {
+        const float4 q = posM[j];
+        const float rSq = dist2_exact(p.x - q.x, p.y - q.y, p.z - q.z);
+        if (rSq < P.h2) {
+            if (cnt < maxNeighbors && lists) lists[(size_t)id * maxNeighbors + cnt] = (int)origId[j];
+            cnt++;
+        }
+    });
+    counts[id] = cnt;
+}
+
+}  // namespace sph

@@ -1,0 +1,44 @@
+// sph_common.h -- shared host/device declarations of libsph_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sph_hip.h"
+
+namespace sph {
+
+constexpr int kBlock = 256;        // threads per workgroup = 4 wave64
+constexpr int kWave = 64;
+
+// Kernel-side copy of the cbuffer (compute:47-81) plus the O4 derived constants, passed by
+// value as a kernel argument (lands in SGPRs / the kernarg segment; no constant-buffer upload).
+struct DevParams {
+    int   n;
+    float dt;
+    float soundSpeed, gamma, h, gravity;
+    float sigma, stThreshold, xsphEps, collisionDamping;
+    float obstacleRadius;
+    float obstaclePos[3];
+    float boundsCenter[3], boundsSize[3];
+    int   rx, ry, rz, cap;
+    float cellSize;
+    float minBound[3];
+    float M[12];      // rows 0..2 of _BoundaryMatrix    (row 3 is never read: compute:351, 396 take .xyz)
+    float Minv[12];   // rows 0..2 of _BoundaryInvMatrix
+    int   obb;        // length(_BoundaryHalfExtents) > 0.001f  (compute:349)
+    // derived once on the host in fp32 (ORACLE rule O4)
+    float h2, poly6, spikyGradFactor, viscLapFactor, lapColFactor;
+};
+
+// SoA particle state, one "set".  Everything is indexed by SLOT (position in the
+// (cell, id)-sorted order of the last grid build; slot == id right after an upload).
+struct StateSet {
+    float4*   posM;    // x, y, z, mass
+    float4*   velV;    // vx, vy, vz, viscosity
+    float4*   acc;     // ax, ay, az, (unused)
+    float2*   rhoP;    // density, pressure
+    float*    rho0;    // rest density
+    uint32_t* origId;  // particle id living in this slot
+};
+
+}  // namespace sph

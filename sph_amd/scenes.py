@@ -1,0 +1,127 @@
+"""Scene definitions: the reference's four Unity scenes (values read from
+Assets/Scenes/Scene{1..4}.unity, tabulated in SURVEY.md section 5.1) and the five BASELINE
+configurations.  Each builder returns a host.Scene driving `engine`.
+"""
+from __future__ import annotations
+
+from .host import (SPH, CircularMotion, RockingMotion, Scene, SpawnBox, SphereCollider, Time, Transform)
+
+WATER = (0.2, 0.5, 1.0, 0.8)
+OIL = (1.0, 0.8, 0.2, 0.8)
+
+# Inspector values shared by Scene1-4 (Scene1.unity:604-622 etc.)
+SCENE_COMMON = dict(soundSpeed=10.0, gamma=4.0, smoothingRadius=0.3, gravity=-9.81, timeStep=0.02, subSteps=1,
+                    surfaceTensionThreshold=0.01, obstacleRepulsionStiffness=100.0, particleCollisionDamping=1.0,
+                    maxParticlesPerCell=500, gridResolution=80, boundsCenter=(0, 5, 0), boundsSize=(10, 10, 10))
+
+
+def _split21(n):
+    """A:B = 2:1 by count: 262,144 -> 174,763 + 87,381."""
+    b = n // 3
+    return n - b, b
+
+
+def _parked_obstacle():
+    # SphereCollider radius 0.5, scale 8 -> radius 4, parked outside the cube (Scene1.unity:676, 740-741)
+    return SphereCollider(radius=0.5, transform=Transform(position=(-6.08, 4.0, 41.53), localScale=(8, 8, 8)))
+
+
+def unity_scene(engine, which: int, scale_count: float = 1.0, seed: int = 12345) -> Scene:
+    """Scene1..Scene4 of the reference. scale_count < 1 shrinks the particle counts (tests)."""
+    def cnt(c):
+        return max(1, int(round(c * scale_count)))
+    time = Time()
+    cube = Transform(position=(0, 15, 0), localScale=(20, 30, 20))                # Scene1.unity:933-935
+    obstacle = _parked_obstacle()
+    movers = []
+    if which in (1, 2):
+        sigma, eps = 0.1, 0.3
+    else:
+        sigma, eps = 0.01, 0.2
+    if which == 1:
+        boxes = [SpawnBox(cnt(200000), (5, 10, 5), 20, 0.1, 0.2, particleColor=WATER, position=(0, 20, 0))]
+    elif which == 2:
+        boxes = [SpawnBox(cnt(150000), (5, 10, 5), 20, 0.01, 0.2, particleColor=WATER, position=(0, 20, 5)),
+                 SpawnBox(cnt(75000), (5, 10, 5), 10, 0.1, 0.2, particleColor=OIL, position=(0, 20, -5))]
+    elif which == 3:
+        boxes = [SpawnBox(cnt(200000), (10, 10, 10), 20, 0.1, 0.2, particleColor=WATER, position=(0, 15, 0))]
+        movers.append(CircularMotion(obstacle.transform, time, center=(0, 0, 0), radius=5.0, speed=2.0))
+    elif which == 4:
+        boxes = [SpawnBox(cnt(150000), (5, 10, 5), 20, 0.1, 0.2, particleColor=WATER, position=(0, 15, 5)),
+                 SpawnBox(cnt(75000), (5, 10, 5), 10, 0.1, 0.2, particleColor=OIL, position=(0, 15, -5))]
+        movers.append(CircularMotion(obstacle.transform, time, center=(0, 0, 0), radius=5.0, speed=1.0))
+    else:
+        raise ValueError("scene 1..4")
+    sph = SPH(engine, **SCENE_COMMON, surfaceTensionCoefficient=sigma, xsphEpsilon=eps, boundaryCube=cube,
+              obstacleCollider=obstacle, spawnBoxes=boxes, seed=seed)
+    return Scene(sph, time, movers)
+
+
+def config1(engine, n=16384, seed=12345) -> Scene:
+    """Config 1: single-phase dam break, AABB-fallback branch, 40^3 cells, no obstacle."""
+    boxes = [SpawnBox(n, (4, 8.2, 5), 20, 0.1, 0.2, particleColor=WATER, position=(-3, 4.1, 0))]
+    f = dict(SCENE_COMMON)
+    f.update(gridResolution=40)
+    sph = SPH(engine, **f, surfaceTensionCoefficient=0.1, xsphEpsilon=0.3, boundaryCube=None, obstacleCollider=None,
+              spawnBoxes=boxes, seed=seed)
+    return Scene(sph, Time(), [])
+
+
+def config2(engine, n=262144, seed=12345) -> Scene:
+    """Config 2: two-phase tank, Scene2/4 geometry, surface tension on, obstacle parked."""
+    a, b = _split21(n)
+    boxes = [SpawnBox(a, (5, 10, 5), 20, 0.1, 0.2, particleColor=WATER, position=(0, 20, 5)),
+             SpawnBox(b, (5, 10, 5), 10, 0.1, 0.2, particleColor=OIL, position=(0, 20, -5))]
+    cube = Transform(position=(0, 15, 0), localScale=(20, 30, 20))
+    sph = SPH(engine, **SCENE_COMMON, surfaceTensionCoefficient=0.1, xsphEpsilon=0.3, boundaryCube=cube,
+              obstacleCollider=_parked_obstacle(), spawnBoxes=boxes, seed=seed)
+    return Scene(sph, Time(), [])
+
+
+def config3(engine, n=1048576, seed=12345, scale=1.6, rocking=True) -> Scene:
+    """Config 3: two-phase + orbiting sphere + rocking cube (Scene4 geometry x1.6)."""
+    a, b = _split21(n)
+    s = scale
+    time = Time()
+    boxes = [SpawnBox(a, (5 * s, 10 * s, 5 * s), 20, 0.1, 0.2, particleColor=WATER, position=(0, 15 * s, 5 * s)),
+             SpawnBox(b, (5 * s, 10 * s, 5 * s), 10, 0.1, 0.2, particleColor=OIL, position=(0, 15 * s, -5 * s))]
+    cube = Transform(position=(0, 15 * s, 0), localScale=(20 * s, 30 * s, 20 * s))
+    obstacle = SphereCollider(radius=0.5, transform=Transform(position=(5 * s, 0, 0), localScale=(8 * s, 8 * s, 8 * s)))
+    movers = [CircularMotion(obstacle.transform, time, center=(0, 0, 0), radius=5.0 * s, speed=1.0)]
+    if rocking:
+        movers.append(RockingMotion(cube, time, amplitude_deg=10.0, rate=0.5))
+    f = dict(SCENE_COMMON)
+    f.update(gridResolution=int(round(80 * s)))
+    sph = SPH(engine, **f, surfaceTensionCoefficient=0.01, xsphEpsilon=0.2, boundaryCube=cube,
+              obstacleCollider=obstacle, spawnBoxes=boxes, seed=seed)
+    return Scene(sph, time, movers)
+
+
+def config4(engine, n=16777216, seed=12345) -> Scene:
+    """Config 4: 16M two-phase tank (strong scaling); single-GPU form."""
+    a, b = _split21(n)
+    boxes = [SpawnBox(a, (78, 10, 20), 20, 0.1, 0.2, particleColor=WATER, position=(0, 60, 12)),
+             SpawnBox(b, (78, 10, 20), 10, 0.1, 0.2, particleColor=OIL, position=(0, 60, -12))]
+    cube = Transform(position=(0, 60, 0), localScale=(80, 120, 80))
+    f = dict(SCENE_COMMON)
+    f.update(gridResolution=320)
+    sph = SPH(engine, **f, surfaceTensionCoefficient=0.01, xsphEpsilon=0.2, boundaryCube=cube, obstacleCollider=None,
+              spawnBoxes=boxes, seed=seed)
+    return Scene(sph, Time(), [])
+
+
+def config5(engine, gpus=1, per_gpu=8388608, seed=12345) -> Scene:
+    """Config 5: weak scaling, 8,388,608 particles per GPU, G blocks of 80 x 96 x 64 along x."""
+    G = gpus
+    a, b = _split21(per_gpu)
+    boxes = []
+    for g in range(G):
+        xc = -40.0 * G + 40.0 + 80.0 * g
+        boxes.append(SpawnBox(a, (76, 8, 13), 20, 0.1, 0.2, particleColor=WATER, position=(xc, 48, 16)))
+        boxes.append(SpawnBox(b, (76, 8, 13), 10, 0.1, 0.2, particleColor=OIL, position=(xc, 48, -16)))
+    cube = Transform(position=(0, 48, 0), localScale=(80 * G, 96, 64))
+    f = dict(SCENE_COMMON)
+    f.update(gridResolution=256)
+    sph = SPH(engine, **f, surfaceTensionCoefficient=0.01, xsphEpsilon=0.2, boundaryCube=cube, obstacleCollider=None,
+              spawnBoxes=boxes, seed=seed)
+    return Scene(sph, Time(), [])
