@@ -109,7 +109,9 @@ enum sph_counter {
 
 typedef struct sph_ctx sph_ctx;
 
-/* Per-stage device time of the most recent sph_step_frame, in milliseconds (hipEvent). */
+/* Per-stage device time in milliseconds (hipEvents on the ctx's stream), AVERAGED over the
+ * sph_step_frame calls since the previous sph_get_timings call (which resets the average).
+ * With subSteps > 1 the sub-step stages are those of the last sub-step. */
 typedef struct sph_timings {
     float build_grid_ms;   /* hash + radix sort + ranges + reorder                */
     float half_step_ms;
@@ -119,6 +121,7 @@ typedef struct sph_timings {
     float bound_obs_ms;
     float damping_ms;
     float frame_ms;        /* whole frame, first launch to last                   */
+    int32_t frames;        /* number of frames averaged                           */
 } sph_timings;
 
 /* ---- lifetime ------------------------------------------------------------------------ */

@@ -98,7 +98,7 @@ class SphPhase(C.Structure):
 
 class SphTimings(C.Structure):
     _fields_ = [(k, C.c_float) for k in ("build_grid_ms", "half_step_ms", "density_ms", "force_ms",
-                                         "full_step_ms", "bound_obs_ms", "damping_ms", "frame_ms")]
+                                         "full_step_ms", "bound_obs_ms", "damping_ms", "frame_ms")] + [("frames", C.c_int32)]
 
 
 def phase_array(phases):

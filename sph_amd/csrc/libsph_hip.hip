@@ -19,7 +19,8 @@ using namespace sph;
 
 namespace {
 
-constexpr int kNumEvents = 10;
+constexpr int kNumEvents = 8;    // stage boundaries of one frame
+constexpr int kTimingRing = 32;  // frames whose events may be outstanding
 
 struct DevBuf {
     void* p = nullptr;
@@ -70,8 +71,13 @@ struct sph_ctx {
     bool haveParams = false;
     DevParams dp{};
 
-    hipEvent_t ev[kNumEvents] = {};
-    bool timingsValid = false;
+    // per-stage hipEvent timing without blocking the host: a ring of event sets, harvested
+    // lazily (when a slot is reused, or in sph_get_timings)
+    hipEvent_t ev[kTimingRing][kNumEvents] = {};
+    bool slotPending[kTimingRing] = {};
+    int ringNext = 0;
+    double stageSum[kNumEvents] = {};   // ms; [7] = whole frame
+    int framesTimed = 0;
 };
 
 namespace {
@@ -181,6 +187,22 @@ int checkReady(sph_ctx* c, bool needGrid) {
     if (c->dp.n != c->n) return fail(c, SPH_E_STATE, "params particleCount %d != allocated %d", c->dp.n, c->n);
     if (!(c->dp.cellSize > 0.0f)) return fail(c, SPH_E_INVALID, "cellSize must be > 0");
     if (needGrid && !c->gridValid) return fail(c, SPH_E_STATE, "grid not built (dispatch CS_BuildGrid first)");
+    return SPH_OK;
+}
+
+int harvestSlot(sph_ctx* c, int slot) {
+    hipEvent_t* ev = c->ev[slot];
+    HIP_TRY(c, hipEventSynchronize(ev[7]));
+    for (int k = 0; k < 7; k++) {
+        float t = 0;
+        HIP_TRY(c, hipEventElapsedTime(&t, ev[k], ev[k + 1]));
+        c->stageSum[k] += t;
+    }
+    float t = 0;
+    HIP_TRY(c, hipEventElapsedTime(&t, ev[0], ev[7]));
+    c->stageSum[7] += t;
+    c->framesTimed++;
+    c->slotPending[slot] = false;
     return SPH_OK;
 }
 
@@ -320,7 +342,8 @@ int sph_create(sph_ctx** out, int device_id) {
         delete c;
         return SPH_E_HIP;
     }
-    for (int k = 0; k < kNumEvents; k++) (void)hipEventCreate(&c->ev[k]);
+    for (int r = 0; r < kTimingRing; r++)
+        for (int k = 0; k < kNumEvents; k++) (void)hipEventCreate(&c->ev[r][k]);
     if (hipMalloc((void**)&c->counters, SPH_CTR_COUNT * sizeof(int)) != hipSuccess ||
         hipMalloc((void**)&c->digitTotal, kRadix * sizeof(uint32_t)) != hipSuccess ||
         hipMemsetAsync(c->counters, 0, SPH_CTR_COUNT * sizeof(int), c->stream) != hipSuccess) {
@@ -340,8 +363,9 @@ int sph_destroy(sph_ctx* c) {
     devFree(c->counters);
     devFree(c->digitTotal);
     devFree(c->phaseTableDev);
-    for (int k = 0; k < kNumEvents; k++)
-        if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
+    for (int r = 0; r < kTimingRing; r++)
+        for (int k = 0; k < kNumEvents; k++)
+            if (c->ev[r][k]) (void)hipEventDestroy(c->ev[r][k]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SPH_OK;
@@ -525,28 +549,32 @@ int sph_step_frame(sph_ctx* c, int sub_steps, float time_step) {
     if (rc) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = applyPhaseTable(c))) return rc;                               // SPH.cs:198
-    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    const int slot = c->ringNext;
+    if (c->slotPending[slot] && (rc = harvestSlot(c, slot))) return rc;
+    hipEvent_t* ev = c->ev[slot];
+    HIP_TRY(c, hipEventRecord(ev[0], c->stream));
     if ((rc = dispatchKernel(c, SPH_K_CLEAR_GRID))) return rc;               // SPH.cs:201
     if ((rc = dispatchKernel(c, SPH_K_BUILD_GRID))) return rc;               // SPH.cs:204
-    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     sph_set_delta_time(c, time_step / (float)sub_steps);                    // SPH.cs:207-208
     for (int s = 0; s < sub_steps; s++) {                                   // SPH.cs:210-219
         const bool last = s == sub_steps - 1;
         if ((rc = dispatchKernel(c, SPH_K_VV_HALF_STEP))) return rc;
-        if (last) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+        if (last) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
         if ((rc = dispatchKernel(c, SPH_K_CLEAR))) return rc;
         if ((rc = dispatchKernel(c, SPH_K_DENSITY_PRESSURE))) return rc;
-        if (last) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+        if (last) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
         if ((rc = dispatchKernel(c, SPH_K_FORCE_XSPH))) return rc;
-        if (last) HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
+        if (last) HIP_TRY(c, hipEventRecord(ev[4], c->stream));
         if ((rc = dispatchKernel(c, SPH_K_VV_FULL_STEP))) return rc;
-        if (last) HIP_TRY(c, hipEventRecord(c->ev[5], c->stream));
+        if (last) HIP_TRY(c, hipEventRecord(ev[5], c->stream));
         if ((rc = dispatchKernel(c, SPH_K_BOUND_OBS))) return rc;
-        if (last) HIP_TRY(c, hipEventRecord(c->ev[6], c->stream));
+        if (last) HIP_TRY(c, hipEventRecord(ev[6], c->stream));
     }
     if ((rc = dispatchKernel(c, SPH_K_VELOCITY_DAMPING))) return rc;         // SPH.cs:222
-    HIP_TRY(c, hipEventRecord(c->ev[7], c->stream));
-    c->timingsValid = true;
+    HIP_TRY(c, hipEventRecord(ev[7], c->stream));
+    c->slotPending[slot] = true;
+    c->ringNext = (slot + 1) % kTimingRing;
     return SPH_OK;
 }
 
@@ -624,20 +652,25 @@ int sph_download_neighbors(sph_ctx* c, int32_t* counts, int32_t* lists, int max_
 int sph_get_timings(sph_ctx* c, sph_timings* out) {
     if (!c) return SPH_E_INVALID;
     if (!out) return fail(c, SPH_E_INVALID, "null timings");
-    if (!c->timingsValid) return fail(c, SPH_E_STATE, "no sph_step_frame has run");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipEventSynchronize(c->ev[7]));
-    float t[8] = {0};
-    for (int k = 0; k < 7; k++) HIP_TRY(c, hipEventElapsedTime(&t[k], c->ev[k], c->ev[k + 1]));
-    HIP_TRY(c, hipEventElapsedTime(&t[7], c->ev[0], c->ev[7]));
-    out->build_grid_ms = t[0];
-    out->half_step_ms = t[1];
-    out->density_ms = t[2];     // includes CS_Clear
-    out->force_ms = t[3];
-    out->full_step_ms = t[4];
-    out->bound_obs_ms = t[5];
-    out->damping_ms = t[6];
-    out->frame_ms = t[7];
+    for (int r = 0; r < kTimingRing; r++)
+        if (c->slotPending[r]) {
+            int rc = harvestSlot(c, r);
+            if (rc) return rc;
+        }
+    if (c->framesTimed == 0) return fail(c, SPH_E_STATE, "no sph_step_frame has run since the last sph_get_timings");
+    const double inv = 1.0 / c->framesTimed;
+    out->build_grid_ms = (float)(c->stageSum[0] * inv);
+    out->half_step_ms = (float)(c->stageSum[1] * inv);
+    out->density_ms = (float)(c->stageSum[2] * inv);     // includes CS_Clear
+    out->force_ms = (float)(c->stageSum[3] * inv);
+    out->full_step_ms = (float)(c->stageSum[4] * inv);
+    out->bound_obs_ms = (float)(c->stageSum[5] * inv);
+    out->damping_ms = (float)(c->stageSum[6] * inv);
+    out->frame_ms = (float)(c->stageSum[7] * inv);
+    out->frames = c->framesTimed;
+    for (int k = 0; k < kNumEvents; k++) c->stageSum[k] = 0;
+    c->framesTimed = 0;
     return SPH_OK;
 }
 
