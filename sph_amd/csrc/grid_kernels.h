@@ -186,6 +186,96 @@ __global__ __launch_bounds__(kBlock) void k_cell_ranges(const uint32_t* __restri
     }
 }
 
+// ---- cumulative cell table: cellCum[c+1] = #particles whose cell index is <= c -----------------------
+// cellEnd[] holds (last slot + 1) for non-empty cells and 0 for empty ones, and those values grow
+// with the cell index, so an inclusive prefix MAX over cells is the running particle count.  With it
+// the bins of any run of consecutive cells [c0, c1] are one slot range [cellCum[c0], cellCum[c1+1]),
+// which is what the 3-cells-per-row neighbour search reads (2 loads per row, empties cost nothing).
+constexpr int kScanItems = 16;
+constexpr int kScanTile = kBlock * kScanItems;   // 4096 cells per block
+
+__device__ __forceinline__ int wave_incl_max(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(v, o);
+        if (lane >= o) v = max(v, t);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_cum_block_max(const int* __restrict__ cellEnd, long long cells,
+                                                          int* __restrict__ blockMax) {
+    __shared__ int ws[4];
+    const long long base = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
+    int m = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; i++) {
+        long long c = base + i;
+        if (c < cells) m = max(m, cellEnd[c]);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    m = wave_incl_max(m, lane);
+    if (lane == 63) ws[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) blockMax[blockIdx.x] = max(max(ws[0], ws[1]), max(ws[2], ws[3]));
+}
+
+// exclusive prefix max over the block maxima, one workgroup
+__global__ __launch_bounds__(kBlock) void k_cum_scan_blocks(int* __restrict__ blockMax, int numBlocks) {
+    __shared__ int ws[4];
+    __shared__ int carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < numBlocks; base += kBlock) {
+        const int i = base + threadIdx.x;
+        const int v = (i < numBlocks) ? blockMax[i] : 0;
+        const int incl = wave_incl_max(v, lane);
+        if (lane == 63) ws[wave] = incl;
+        __syncthreads();
+        int off = carry;
+        for (int w = 0; w < wave; w++) off = max(off, ws[w]);
+        int excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 0;
+        excl = max(excl, off);
+        if (i < numBlocks) blockMax[i] = excl;
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) carry = max(off, incl);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_cum_write(const int* __restrict__ cellEnd, long long cells,
+                                                      const int* __restrict__ blockPrefix,
+                                                      int* __restrict__ cellCum) {
+    __shared__ int ws[4];
+    const long long base = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
+    int v[kScanItems];
+    int m = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; i++) {
+        long long c = base + i;
+        v[i] = (c < cells) ? cellEnd[c] : 0;
+        m = max(m, v[i]);
+        v[i] = m;                       // thread-local inclusive max
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int incl = wave_incl_max(m, lane);
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    int off = blockPrefix[blockIdx.x];
+    for (int w = 0; w < wave; w++) off = max(off, ws[w]);
+    int excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = 0;
+    off = max(off, excl);
+    if (blockIdx.x == 0 && threadIdx.x == 0) cellCum[0] = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; i++) {
+        long long c = base + i;
+        if (c < cells) cellCum[c + 1] = max(off, v[i]);
+    }
+}
+
 // sid[k] = id of the particle that the cell-sorted rank k refers to
 __global__ __launch_bounds__(kBlock) void k_gather_ids(const uint32_t* __restrict__ perm,
                                                        const uint32_t* __restrict__ origId, int n,

@@ -52,6 +52,8 @@ struct sph_ctx {
     long long cellCapacity = 0;
     int* cellStart = nullptr;
     int* cellEnd = nullptr;
+    int* cellCum = nullptr;           // [cells + 1] running particle count by cell
+    int* cumBlocks = nullptr;         // per-4096-cell block maxima / prefixes
     uint32_t* keys[2] = {nullptr, nullptr};
     uint32_t* vals[2] = {nullptr, nullptr};
     uint32_t* sid = nullptr;
@@ -132,7 +134,7 @@ void freeParticles(sph_ctx* c) {
 }
 
 void freeGrid(sph_ctx* c) {
-    devFree(c->cellStart); devFree(c->cellEnd);
+    devFree(c->cellStart); devFree(c->cellEnd); devFree(c->cellCum); devFree(c->cumBlocks);
     c->cellCapacity = 0; c->cells = 0;
 }
 
@@ -265,6 +267,13 @@ int buildGrid(sph_ctx* c) {
     uint32_t* perm = c->vals[in];
     hipLaunchKernelGGL(k_cell_ranges, dim3(nb), dim3(kBlock), 0, c->stream, c->sortedKeys, n, c->cellStart,
                        c->cellEnd);
+    {   // cumulative cell table for the 3-cells-per-row search
+        const int cb = (int)((c->cells + kScanTile - 1) / kScanTile);
+        hipLaunchKernelGGL(k_cum_block_max, dim3(cb), dim3(kBlock), 0, c->stream, c->cellEnd, c->cells, c->cumBlocks);
+        hipLaunchKernelGGL(k_cum_scan_blocks, dim3(1), dim3(kBlock), 0, c->stream, c->cumBlocks, cb);
+        hipLaunchKernelGGL(k_cum_write, dim3(cb), dim3(kBlock), 0, c->stream, c->cellEnd, c->cells, c->cumBlocks,
+                           c->cellCum);
+    }
     hipLaunchKernelGGL(k_gather_ids, dim3(nb), dim3(kBlock), 0, c->stream, perm, src.origId, n, c->sid);
     StateSet dst = c->set[1 - c->cur];
     // velocities of the new order go to the set that does NOT hold the current ones
@@ -292,13 +301,17 @@ int dispatchKernel(sph_ctx* c, int id) {
         case SPH_K_BUILD_GRID:
             return buildGrid(c);
         case SPH_K_DENSITY_PRESSURE:
+            hipLaunchKernelGGL(k_density_pressure_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.rho0,
+                               s.rhoP, c->cellCum, c->counters);
             hipLaunchKernelGGL(k_density_pressure, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.rho0, s.rhoP,
-                               c->cellStart, c->cellEnd);
+                               c->cellStart, c->cellEnd, c->counters);
             break;
         case SPH_K_FORCE_XSPH: {
             float4* velOut = c->set[1 - c->velCur].velV;
+            hipLaunchKernelGGL(k_force_xsph_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, s.rhoP,
+                               s.acc, velOut, c->cellCum, c->counters);
             hipLaunchKernelGGL(k_force_xsph, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, s.rhoP, s.acc,
-                               velOut, c->cellStart, c->cellEnd);
+                               velOut, c->cellStart, c->cellEnd, c->counters);
             c->velCur = 1 - c->velCur;
             break;
         }
@@ -462,6 +475,8 @@ int sph_resize_grid(sph_ctx* c, int rx, int ry, int rz, int max_per_cell) {
         if (want > 0x7FFFFFFFll) want = 0x7FFFFFFFll;
         int rc = devAlloc(c, &c->cellStart, (size_t)want);
         if (!rc) rc = devAlloc(c, &c->cellEnd, (size_t)want);
+        if (!rc) rc = devAlloc(c, &c->cellCum, (size_t)want + 1);
+        if (!rc) rc = devAlloc(c, &c->cumBlocks, (size_t)((want + kScanTile - 1) / kScanTile));
         if (rc) { freeGrid(c); return rc; }
         c->cellCapacity = want;
     }
@@ -638,7 +653,7 @@ int sph_download_neighbors(sph_ctx* c, int32_t* counts, int32_t* lists, int max_
     }
     StateSet s = curSet(c);
     hipLaunchKernelGGL(k_export_neighbors, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.origId,
-                       c->cellStart, c->cellEnd, dCounts, dLists, max_neighbors);
+                       c->cellStart, c->cellEnd, c->cellCum, c->counters, dCounts, dLists, max_neighbors);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(counts, dCounts, sizeof(int) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess && dLists) e = hipMemcpyAsync(lists, dLists, lb, hipMemcpyDeviceToHost, c->stream);

@@ -24,7 +24,12 @@ template <class F>
 __device__ __forceinline__ void for_each_candidate(const DevParams& P, const int* __restrict__ cellStart,
                                                    const int* __restrict__ cellEnd, int self, float px, float py,
                                                    float pz, F&& f) {
-    const int3 c = cell_unclamped(P, px, py, pz);
+    int3 c = cell_unclamped(P, px, py, pz);
+    // cells further than 1 outside the grid have no in-range neighbour cell; clamping them to
+    // [-2, r+1] keeps that and avoids signed overflow on saturated coordinates
+    c.x = min(max(c.x, -2), P.rx + 1);
+    c.y = min(max(c.y, -2), P.ry + 1);
+    c.z = min(max(c.z, -2), P.rz + 1);
     for (int z = c.z - 1; z <= c.z + 1; z++) {
         if (z < 0 || z >= P.rz) continue;
         for (int y = c.y - 1; y <= c.y + 1; y++) {
@@ -52,12 +57,15 @@ __global__ __launch_bounds__(kBlock) void k_clear(int n, float4* __restrict__ ac
     rhoP[s] = make_float2(rho0[s], 0.f);
 }
 
-// CS_DensityPressure (compute:142-193)
+// CS_DensityPressure (compute:142-193), per-cell path with the bin cap (rule O2): runs only when
+// some bin overflowed at the last grid build.
 __global__ __launch_bounds__(kBlock) void k_density_pressure(DevParams P, const float4* __restrict__ posM,
                                                              const float* __restrict__ rho0,
                                                              float2* __restrict__ rhoP,
                                                              const int* __restrict__ cellStart,
-                                                             const int* __restrict__ cellEnd) {
+                                                             const int* __restrict__ cellEnd,
+                                                             const int* __restrict__ counters) {
+    if (counters[SPH_CTR_BIN_OVERFLOW] == 0) return;      // the fast path ran
     int s = blockIdx.x * kBlock + threadIdx.x;
     if (s >= P.n) return;
     const float4 p = posM[s];
@@ -86,7 +94,9 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph(DevParams P, const float4
                                                        const float2* __restrict__ rhoP, float4* __restrict__ acc,
                                                        float4* __restrict__ velOut,
                                                        const int* __restrict__ cellStart,
-                                                       const int* __restrict__ cellEnd) {
+                                                       const int* __restrict__ cellEnd,
+                                                       const int* __restrict__ counters) {
+    if (counters[SPH_CTR_BIN_OVERFLOW] == 0) return;      // the fast path ran
     int s = blockIdx.x * kBlock + threadIdx.x;
     if (s >= P.n) return;
     const float4 p = posM[s];
@@ -146,6 +156,188 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph(DevParams P, const float4
         vo.x += vcx * sc; vo.y += vcy * sc; vo.z += vcz * sc;
     }
     velOut[s] = vo;
+}
+
+
+// ---- fast path: no bin overflowed (counters[SPH_CTR_BIN_OVERFLOW] == 0) ---------------------------------
+// The three x-neighbour cells of one (y, z) row are adjacent in the linear cell index
+// (compute:127), hence adjacent in the sorted order: their bins are ONE slot range, read from the
+// cumulative table with two loads.  Visiting order is unchanged: z, y, then x-1, x, x+1, then id.
+struct RowRange { int a, e; };
+
+__device__ __forceinline__ int3 search_cell(const DevParams& P, float px, float py, float pz) {
+    int3 c = cell_unclamped(P, px, py, pz);
+    c.x = min(max(c.x, -2), P.rx + 1);
+    c.y = min(max(c.y, -2), P.ry + 1);
+    c.z = min(max(c.z, -2), P.rz + 1);
+    return c;
+}
+
+__device__ __forceinline__ RowRange row_range(const DevParams& P, const int* __restrict__ cellCum, int3 c, int dy,
+                                              int dz, bool live) {
+    const int y = c.y + dy, z = c.z + dz;
+    const int xlo = max(c.x - 1, 0), xhi = min(c.x + 1, P.rx - 1);
+    RowRange r{0, 0};
+    if (live && y >= 0 && y < P.ry && z >= 0 && z < P.rz && xlo <= xhi) {
+        const int base = y * P.rx + z * P.rx * P.ry;
+        r.a = cellCum[base + xlo];
+        r.e = cellCum[base + xhi + 1];
+    }
+    return r;
+}
+
+// CS_DensityPressure (compute:142-193), fast path.  Same operations in the same order as the
+// per-cell kernel below, so the density is bit-identical to the oracle's.
+__global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, const float4* __restrict__ posM,
+                                                                  const float* __restrict__ rho0,
+                                                                  float2* __restrict__ rhoP,
+                                                                  const int* __restrict__ cellCum,
+                                                                  const int* __restrict__ counters) {
+    if (counters[SPH_CTR_BIN_OVERFLOW] != 0) return;      // the capped per-cell kernel runs instead
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= P.n) return;
+    const float4 p = posM[s];
+    const int3 c = search_cell(P, p.x, p.y, p.z);
+    float density = 0.0f;
+#pragma unroll 1
+    for (int dz = -1; dz <= 1; dz++) {
+#pragma unroll 1
+        for (int dy = -1; dy <= 1; dy++) {
+            const RowRange r = row_range(P, cellCum, c, dy, dz, true);
+            for (int j = r.a; j < r.e; j++) {
+                const float4 q = posM[j];
+                const float rSq = dist2_exact(p.x - q.x, p.y - q.y, p.z - q.z);
+                if (rSq < P.h2 && j != s) {
+                    const float diff = P.h2 - rSq;
+                    density += q.w * P.poly6 * diff * diff * diff;     // compute:180
+                }
+            }
+        }
+    }
+    const float r0 = rho0[s];
+    density = fmaxf(density, r0);                                          // compute:186
+    const float localB = r0 * (P.soundSpeed * P.soundSpeed) / P.gamma;     // compute:189
+    const float pressure = localB * (powf(density / r0, P.gamma) - 1.0f);  // compute:190
+    rhoP[s] = make_float2(density, pressure);
+}
+
+// One in-range pair of CS_ForceXSPH (compute:250-277) with FMA contraction and hardware
+// reciprocals / square root (1 ulp) instead of the 12 IEEE divides of the literal form; the
+// result is tolerance-checked against the oracle (1e-5 of field scale), not bit-compared.
+struct ForceAcc {
+    float fx, fy, fz, cgx, cgy, cgz, cl, vcx, vcy, vcz, norm;
+};
+
+__device__ __forceinline__ void force_pair(const DevParams& P, ForceAcc& A, const float4 p, const float4 v,
+                                           float densitySelf, float selfTerm, const float4 q, const float4 u,
+                                           const float2 o) {
+#pragma clang fp contract(fast)
+    const float rx = p.x - q.x, ry = p.y - q.y, rz = p.z - q.z;
+    const float rSq = dist2_exact(rx, ry, rz);
+    const float dist = __builtin_amdgcn_sqrtf(rSq) + 1e-6f;               // compute:250
+    const float invd = __builtin_amdgcn_rcpf(dist);
+    const float invRho = __builtin_amdgcn_rcpf(o.x);
+    const float diff = P.h2 - rSq;
+    const float pressureTerm = selfTerm + o.y * invRho * invRho;          // compute:255-256
+    const float gs = P.spikyGradFactor * diff * diff * invd;              // gradW = gs * r  (compute:257)
+    const float gwx = gs * rx, gwy = gs * ry, gwz = gs * rz;
+    const float pf = -q.w * pressureTerm;
+    const float dvx = u.x - v.x, dvy = u.y - v.y, dvz = u.z - v.z;        // compute:261
+    const float mor = q.w * invRho;                                       // m_j / rho_j
+    const float vm = 0.5f * (v.w + u.w) * mor * (P.viscLapFactor * (P.h - dist));   // compute:263-265
+    A.fx += pf * gwx + vm * dvx;                                          // compute:258, 265
+    A.fy += pf * gwy + vm * dvy;
+    A.fz += pf * gwz + vm * dvz;
+    A.cgx += mor * gwx; A.cgy += mor * gwy; A.cgz += mor * gwz;           // compute:268
+    A.cl += mor * (-P.lapColFactor * diff * (P.h2 - 5.0f * rSq));         // compute:269-270
+    const float wm = P.poly6 * diff * diff * diff * q.w * __builtin_amdgcn_rcpf(0.5f * (densitySelf + o.x));
+    A.vcx += dvx * wm; A.vcy += dvy * wm; A.vcz += dvz * wm;              // compute:276
+    A.norm += wm;                                                         // compute:277
+}
+
+// CS_ForceXSPH (compute:199-303), fast path.  Two phases per wave so that the expensive pair
+// arithmetic runs with (nearly) full lanes although only ~1/4 of the candidates are in range:
+//   scan : every lane walks its candidates, does the exact rSq < h2 test, and appends hits to its
+//          own FIFO in LDS (queue[k][thread], conflict-free);
+//   drain: when any lane's FIFO is full (wave ballot), all lanes pop their hits in order and do
+//          the pair arithmetic.  FIFO order = visiting order, so each lane still sums its
+//          neighbours in the reference's order.
+constexpr int kHitQueue = 16;
+
+__global__ __launch_bounds__(kBlock) void k_force_xsph_rows(DevParams P, const float4* __restrict__ posM,
+                                                            const float4* __restrict__ velIn,
+                                                            const float2* __restrict__ rhoP,
+                                                            float4* __restrict__ acc, float4* __restrict__ velOut,
+                                                            const int* __restrict__ cellCum,
+                                                            const int* __restrict__ counters) {
+    __shared__ int queue[kHitQueue][kBlock];
+    if (counters[SPH_CTR_BIN_OVERFLOW] != 0) return;      // the capped per-cell kernel runs instead
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = s < P.n;
+    const int sl = valid ? s : 0;
+    const float4 p = posM[sl];
+    const float4 v = velIn[sl];
+    const float2 dp = rhoP[sl];
+    const float densitySelf = dp.x;
+    const bool live = valid && !(densitySelf < 1e-6f);                     // compute:207-211
+    const float selfTerm = dp.y / (densitySelf * densitySelf);
+    ForceAcc A{0.0f, P.gravity * densitySelf, 0.0f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // compute:219
+    const int3 c = search_cell(P, p.x, p.y, p.z);
+    int cnt = 0;
+    auto drain = [&]() {
+#pragma unroll 1
+        for (int k = 0; k < kHitQueue; k++) {
+            if (!__any(k < cnt)) break;
+            if (k < cnt) {
+                const int j = queue[k][threadIdx.x];
+                force_pair(P, A, p, v, densitySelf, selfTerm, posM[j], velIn[j], rhoP[j]);
+            }
+        }
+        cnt = 0;
+    };
+#pragma unroll 1
+    for (int dz = -1; dz <= 1; dz++) {
+#pragma unroll 1
+        for (int dy = -1; dy <= 1; dy++) {
+            const RowRange r = row_range(P, cellCum, c, dy, dz, live);
+            int j = r.a;
+            while (__any(j < r.e)) {
+                if (j < r.e) {
+                    const float4 q = posM[j];
+                    const float rSq = dist2_exact(p.x - q.x, p.y - q.y, p.z - q.z);
+                    if (rSq < P.h2 && j != s) {
+                        queue[cnt][threadIdx.x] = j;
+                        cnt++;
+                    }
+                }
+                j++;
+                if (__any(cnt == kHitQueue)) drain();
+            }
+        }
+    }
+    drain();
+    if (!valid) return;
+    if (!live) {
+        velOut[s] = v;
+        return;
+    }
+    {
+#pragma clang fp contract(fast)
+        const float gradMag = sqrtf((A.cgx * A.cgx + A.cgy * A.cgy) + A.cgz * A.cgz);   // compute:285
+        if (gradMag > P.stThreshold) {
+            const float curvature = A.cl / (gradMag + 1e-6f);
+            const float st = -P.sigma * curvature / gradMag;
+            A.fx += st * A.cgx; A.fy += st * A.cgy; A.fz += st * A.cgz;
+        }
+        const float invD = 1.0f / densitySelf;
+        acc[s] = make_float4(A.fx * invD, A.fy * invD, A.fz * invD, 0.f);            // compute:293
+        float4 vo = v;
+        if (A.norm > 1e-6f) {                                                        // compute:296-300
+            const float sc = P.xsphEps / A.norm;
+            vo.x += A.vcx * sc; vo.y += A.vcy * sc; vo.z += A.vcz * sc;
+        }
+        velOut[s] = vo;
+    }
 }
 
 // CS_VvHalfStep (compute:309-319)
@@ -323,11 +515,14 @@ __global__ __launch_bounds__(kBlock) void k_apply_phase_table(int n, StateSet st
     color[id] = make_float4(ph.color[0], ph.color[1], ph.color[2], ph.color[3]);
 }
 
-// Neighbour-list export (parity only): what CS_DensityPressure's loop would accept right now.
+// Neighbour-list export (parity only): what CS_DensityPressure's loop accepts right now, walked the
+// same way the production kernels walk it (row ranges when no bin overflowed, capped cells otherwise).
 __global__ __launch_bounds__(kBlock) void k_export_neighbors(DevParams P, const float4* __restrict__ posM,
                                                              const uint32_t* __restrict__ origId,
                                                              const int* __restrict__ cellStart,
                                                              const int* __restrict__ cellEnd,
+                                                             const int* __restrict__ cellCum,
+                                                             const int* __restrict__ counters,
                                                              int* __restrict__ counts, int* __restrict__ lists,
                                                              int maxNeighbors) {
     int s = blockIdx.x * kBlock + threadIdx.x;
@@ -335,14 +530,25 @@ __global__ __launch_bounds__(kBlock) void k_export_neighbors(DevParams P, const 
     const float4 p = posM[s];
     const uint32_t id = origId[s];
     int cnt = 0;
-    for_each_candidate(P, cellStart, cellEnd, s, p.x, p.y, p.z, [&](int j) {
+    auto visit = [&](int j) {
         const float4 q = posM[j];
         const float rSq = dist2_exact(p.x - q.x, p.y - q.y, p.z - q.z);
         if (rSq < P.h2) {
             if (cnt < maxNeighbors && lists) lists[(size_t)id * maxNeighbors + cnt] = (int)origId[j];
             cnt++;
         }
-    });
+    };
+    if (counters[SPH_CTR_BIN_OVERFLOW] == 0) {
+        const int3 c = search_cell(P, p.x, p.y, p.z);
+        for (int dz = -1; dz <= 1; dz++)
+            for (int dy = -1; dy <= 1; dy++) {
+                const RowRange r = row_range(P, cellCum, c, dy, dz, true);
+                for (int j = r.a; j < r.e; j++)
+                    if (j != s) visit(j);
+            }
+    } else {
+        for_each_candidate(P, cellStart, cellEnd, s, p.x, p.y, p.z, visit);
+    }
     counts[id] = cnt;
 }
 
