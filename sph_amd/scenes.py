@@ -27,9 +27,15 @@ def _parked_obstacle():
 
 
 def unity_scene(engine, which: int, scale_count: float = 1.0, seed: int = 12345) -> Scene:
-    """Scene1..Scene4 of the reference. scale_count < 1 shrinks the particle counts (tests)."""
+    """Scene1..Scene4 of the reference.  scale_count < 1 (tests) shrinks the particle counts and
+    the spawn boxes together, so the spawn number density stays the scene's own."""
+    ls = float(scale_count) ** (1.0 / 3.0)
+
     def cnt(c):
         return max(1, int(round(c * scale_count)))
+
+    def sz(x, y, z):
+        return (x * ls, y * ls, z * ls)
     time = Time()
     cube = Transform(position=(0, 15, 0), localScale=(20, 30, 20))                # Scene1.unity:933-935
     obstacle = _parked_obstacle()
@@ -39,16 +45,16 @@ def unity_scene(engine, which: int, scale_count: float = 1.0, seed: int = 12345)
     else:
         sigma, eps = 0.01, 0.2
     if which == 1:
-        boxes = [SpawnBox(cnt(200000), (5, 10, 5), 20, 0.1, 0.2, particleColor=WATER, position=(0, 20, 0))]
+        boxes = [SpawnBox(cnt(200000), sz(5, 10, 5), 20, 0.1, 0.2, particleColor=WATER, position=(0, 20, 0))]
     elif which == 2:
-        boxes = [SpawnBox(cnt(150000), (5, 10, 5), 20, 0.01, 0.2, particleColor=WATER, position=(0, 20, 5)),
-                 SpawnBox(cnt(75000), (5, 10, 5), 10, 0.1, 0.2, particleColor=OIL, position=(0, 20, -5))]
+        boxes = [SpawnBox(cnt(150000), sz(5, 10, 5), 20, 0.01, 0.2, particleColor=WATER, position=(0, 20, 5)),
+                 SpawnBox(cnt(75000), sz(5, 10, 5), 10, 0.1, 0.2, particleColor=OIL, position=(0, 20, -5))]
     elif which == 3:
-        boxes = [SpawnBox(cnt(200000), (10, 10, 10), 20, 0.1, 0.2, particleColor=WATER, position=(0, 15, 0))]
+        boxes = [SpawnBox(cnt(200000), sz(10, 10, 10), 20, 0.1, 0.2, particleColor=WATER, position=(0, 15, 0))]
         movers.append(CircularMotion(obstacle.transform, time, center=(0, 0, 0), radius=5.0, speed=2.0))
     elif which == 4:
-        boxes = [SpawnBox(cnt(150000), (5, 10, 5), 20, 0.1, 0.2, particleColor=WATER, position=(0, 15, 5)),
-                 SpawnBox(cnt(75000), (5, 10, 5), 10, 0.1, 0.2, particleColor=OIL, position=(0, 15, -5))]
+        boxes = [SpawnBox(cnt(150000), sz(5, 10, 5), 20, 0.1, 0.2, particleColor=WATER, position=(0, 15, 5)),
+                 SpawnBox(cnt(75000), sz(5, 10, 5), 10, 0.1, 0.2, particleColor=OIL, position=(0, 15, -5))]
         movers.append(CircularMotion(obstacle.transform, time, center=(0, 0, 0), radius=5.0, speed=1.0))
     else:
         raise ValueError("scene 1..4")

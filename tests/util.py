@@ -47,3 +47,70 @@ def assert_neighbors_equal(eng, ora, max_nb=512, what=""):
     assert int(oc.max(initial=0)) <= max_nb
     assert np.array_equal(el, ol), what + "neighbour lists differ"
     return oc
+
+
+# ---- golden fixtures (tests/golden/*.npz, written by tests/golden/make_golden.py) ----------------
+import ctypes as _C
+import glob as _glob
+import os as _os
+
+GOLDEN_DIR = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
+
+
+def golden_cases():
+    return sorted(_os.path.splitext(_os.path.basename(p))[0] for p in _glob.glob(_os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    fx = dict(np.load(_os.path.join(GOLDEN_DIR, name + ".npz")))
+    p = abi.SphParams()
+    raw = fx["params"].tobytes()
+    assert len(raw) == _C.sizeof(abi.SphParams), "fixture was written with a different sph_params layout"
+    _C.memmove(_C.byref(p), raw, len(raw))
+    fx["params_struct"] = p
+    return fx
+
+
+def replay_golden(engine, fx):
+    """Upload the fixture's input state, run ONE frame through the engine-like object."""
+    p = fx["params_struct"]
+    n = fx["state_in"].shape[0]
+    engine.alloc_particles(n)
+    engine.upload_particles(fx["state_in"])
+    engine.resize_grid(p.gridResolutionX, p.gridResolutionY, p.gridResolutionZ, p.maxParticlesPerCell)
+    engine.set_params(p)
+    for k in range(3):
+        engine.reset_counter(k)
+    engine.step_frame(int(fx["sub_steps"]), float(fx["time_step"]))
+
+
+def golden_neighbor_lists(fx):
+    cnt, flat = fx["neighbor_counts"], fx["neighbor_flat"]
+    off = np.r_[0, np.cumsum(cnt)]
+    return [flat[off[i]:off[i + 1]] for i in range(len(cnt))]
+
+
+def check_against_golden(engine, fx, tol, exact_fields=False, what=""):
+    cap = int(fx["params_struct"].maxParticlesPerCell)
+    cs, ce, ids, cop = engine.download_grid()[:4]
+    assert np.array_equal(cop, fx["cell_of_particle"]), what + "cell hash differs"
+    nz = fx["grid_counts_nonzero_cells"]
+    counts = np.zeros(cs.shape[0], dtype=np.int32)
+    counts[nz] = fx["grid_counts_nonzero"]
+    overflow = int(counts.max(initial=0)) > cap
+    if not overflow:
+        assert np.array_equal(ce - cs, counts), what + "cell populations differ"
+        assert np.array_equal(ids, fx["sorted_ids"]), what + "sorted ids differ"
+    ncnt, nlst = engine.download_neighbors(512)
+    gl = golden_neighbor_lists(fx)
+    assert np.array_equal(ncnt, fx["neighbor_counts"]), what + "neighbour counts differ"
+    for i, want in enumerate(gl):
+        if not np.array_equal(nlst[i, :len(want)], want):
+            raise AssertionError(what + f"neighbour list of particle {i} differs")
+    got, want = engine.download_particles(), fx["state_out"]
+    if exact_fields:
+        assert np.array_equal(got, want), what + "state differs bitwise"
+    else:
+        assert_fields_close(got, want, tol, what)
+    ctr = [engine.read_counter(k) for k in range(3)]
+    assert ctr == fx["counters"].tolist(), what + f"counters {ctr} != {fx['counters'].tolist()}"
