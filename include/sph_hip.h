@@ -104,7 +104,9 @@ enum sph_counter {
                                  last grid build (compute:131 drops those ids)            */
     SPH_CTR_OUT_OF_GRID  = 2, /* #particles whose unclamped cell was outside the grid at
                                  the last grid build (compute:126 clamps them)            */
-    SPH_CTR_COUNT        = 3
+    SPH_CTR_MAX_PLANE_SHIFT = 3, /* slab mode: max |search plane - binned plane| over the local
+                                 particles in the last CS_DensityPressure (halo-width check)     */
+    SPH_CTR_COUNT        = 4
 };
 
 typedef struct sph_ctx sph_ctx;
@@ -194,6 +196,41 @@ int  sph_get_timings(sph_ctx* ctx, sph_timings* out);
 int  sph_device_pointer(sph_ctx* ctx, const char* name, void** ptr, uint64_t* bytes);
 /* The HIP stream the ctx enqueues on (hipStream_t as void*). */
 int  sph_get_stream(sph_ctx* ctx, void** stream);
+
+/* ---- multi-GPU slab decomposition (no reference counterpart: the reference is single-GPU) ----------
+ * One ctx per GPU holds the particles of an x-slab of whole cell planes of the GLOBAL grid plus ghost
+ * copies of the neighbouring planes.  sph_params.gridResolutionX stays the GLOBAL x resolution;
+ * sph_resize_grid gets the LOCAL one (owned + ghost planes).  Particle ids are global.  See
+ * sph_amd/slab.py for the per-frame protocol (one message per slab face per frame). */
+typedef struct sph_slab_record {       /* 64 bytes: what travels between slabs */
+    float    pos[3], mass;
+    float    vel[3], viscosity;
+    float    acc[3], restDensity;
+    uint32_t id;                        /* global particle id */
+    float    density, pressure;
+    uint32_t phase;
+} sph_slab_record;
+
+/* Local grid = global planes [x_offset, x_offset + rx_local) (rx_local from sph_resize_grid); planes
+ * [own_lo, own_hi) (GLOBAL coordinates) are owned.  rx_global <= 0 switches slab mode off. */
+int  sph_slab_configure(sph_ctx* ctx, int rx_global, int x_offset, int own_lo, int own_hi);
+/* Capacity-based allocation for a slab whose population changes every frame. */
+int  sph_slab_reserve(sph_ctx* ctx, int capacity);
+/* Replace the local set by n records from host memory (initial distribution). */
+int  sph_slab_upload(sph_ctx* ctx, const sph_slab_record* records, int n);
+/* Local particles (owned only, or owned + ghosts) as records, to host memory.  Synchronises. */
+int  sph_slab_download(sph_ctx* ctx, sph_slab_record* records, int max_records, int owned_only, int* n);
+/* Pack the face messages into DEVICE buffers: owned particles whose current global plane is
+ * < left_below go to dev_left, >= right_from to dev_right.  Counts may exceed the capacities
+ * (then the message is truncated and the call fails).  Synchronises. */
+int  sph_slab_pack(sph_ctx* ctx, int left_below, int right_from, void* dev_left, int cap_left,
+                   void* dev_right, int cap_right, int* n_left, int* n_right);
+/* New local set = owned particles whose current global plane is in [keep_lo, keep_hi) + the received
+ * records (DEVICE buffers) in that plane range.  Last frame's ghosts are dropped.  Synchronises. */
+int  sph_slab_rebuild(sph_ctx* ctx, int keep_lo, int keep_hi, const void* dev_from_left, int n_from_left,
+                      const void* dev_from_right, int n_from_right, int* n_local);
+/* Current local particle count (owned + ghosts). */
+int  sph_particle_count(sph_ctx* ctx, int* n);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,8 @@ K_CLEAR, K_CLEAR_GRID, K_BUILD_GRID, K_DENSITY_PRESSURE, K_FORCE_XSPH, K_VV_HALF
 KERNEL_NAMES = ["CS_Clear", "CS_ClearGrid", "CS_BuildGrid", "CS_DensityPressure", "CS_ForceXSPH",
                 "CS_VvHalfStep", "CS_VvFullStep", "CS_BoundObs", "CS_VelocityDamping"]
 
-CTR_COLLISIONS, CTR_BIN_OVERFLOW, CTR_OUT_OF_GRID = range(3)
+CTR_COLLISIONS, CTR_BIN_OVERFLOW, CTR_OUT_OF_GRID, CTR_MAX_PLANE_SHIFT = range(4)
+SLAB_RECORD_BYTES = 64
 
 # every symbol include/sph_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -29,7 +30,8 @@ EXPORTS = [
     "sph_set_delta_time", "sph_set_phase_table", "sph_set_phase_ids", "sph_apply_phase_table",
     "sph_dispatch", "sph_step_frame", "sph_synchronize", "sph_reset_counter", "sph_read_counter",
     "sph_download_grid", "sph_download_neighbors", "sph_get_timings", "sph_device_pointer",
-    "sph_get_stream",
+    "sph_get_stream", "sph_slab_configure", "sph_slab_reserve", "sph_slab_upload", "sph_slab_download",
+    "sph_slab_pack", "sph_slab_rebuild", "sph_particle_count",
 ]
 
 
@@ -160,6 +162,13 @@ def load_library() -> C.CDLL:
     lib.sph_get_timings.argtypes = [vp, C.POINTER(SphTimings)]
     lib.sph_device_pointer.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)]
     lib.sph_get_stream.argtypes = [vp, C.POINTER(vp)]
+    lib.sph_slab_configure.argtypes = [vp, ip, ip, ip, ip]
+    lib.sph_slab_reserve.argtypes = [vp, ip]
+    lib.sph_slab_upload.argtypes = [vp, vp, ip]
+    lib.sph_slab_download.argtypes = [vp, vp, ip, ip, C.POINTER(ip)]
+    lib.sph_slab_pack.argtypes = [vp, ip, ip, vp, ip, vp, ip, C.POINTER(ip), C.POINTER(ip)]
+    lib.sph_slab_rebuild.argtypes = [vp, ip, ip, vp, ip, vp, ip, C.POINTER(ip)]
+    lib.sph_particle_count.argtypes = [vp, C.POINTER(ip)]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("sph_last_error", "sph_version"):
@@ -280,7 +289,70 @@ class Engine:
         self._ck(self.lib.sph_device_pointer(self.h, name.encode(), C.byref(p), C.byref(b)))
         return p.value, b.value
 
+    # -- slab decomposition
+    def slab_configure(self, rx_global, x_offset, own_lo, own_hi):
+        self._ck(self.lib.sph_slab_configure(self.h, rx_global, x_offset, own_lo, own_hi))
+
+    def slab_reserve(self, capacity):
+        self._ck(self.lib.sph_slab_reserve(self.h, capacity))
+
+    def slab_upload(self, records: np.ndarray):
+        records = np.ascontiguousarray(records, dtype=SLAB_RECORD_DTYPE)
+        self._ck(self.lib.sph_slab_upload(self.h, _ptr(records), records.shape[0]))
+        self.n = records.shape[0]
+
+    def slab_download(self, owned_only=True) -> np.ndarray:
+        out = np.zeros(max(self.particle_count(), 1), dtype=SLAB_RECORD_DTYPE)
+        n = C.c_int(0)
+        self._ck(self.lib.sph_slab_download(self.h, _ptr(out), out.shape[0], int(owned_only), C.byref(n)))
+        return out[:n.value]
+
+    def slab_pack(self, left_below, right_from, dev_left, cap_left, dev_right, cap_right):
+        nl, nr = C.c_int(0), C.c_int(0)
+        self._ck(self.lib.sph_slab_pack(self.h, left_below, right_from, dev_left, cap_left, dev_right, cap_right,
+                                        C.byref(nl), C.byref(nr)))
+        return nl.value, nr.value
+
+    def slab_rebuild(self, keep_lo, keep_hi, dev_left, n_left, dev_right, n_right) -> int:
+        n = C.c_int(0)
+        self._ck(self.lib.sph_slab_rebuild(self.h, keep_lo, keep_hi, dev_left, n_left, dev_right, n_right, C.byref(n)))
+        self.n = n.value
+        return n.value
+
+    def particle_count(self) -> int:
+        n = C.c_int(0)
+        self._ck(self.lib.sph_particle_count(self.h, C.byref(n)))
+        return n.value
+
     def get_stream(self) -> int:
         s = C.c_void_p()
         self._ck(self.lib.sph_get_stream(self.h, C.byref(s)))
         return s.value or 0
+
+
+# numpy view of struct sph_slab_record (64 B)
+SLAB_RECORD_DTYPE = np.dtype([("pos", np.float32, 3), ("mass", np.float32), ("vel", np.float32, 3),
+                              ("viscosity", np.float32), ("acc", np.float32, 3), ("restDensity", np.float32),
+                              ("id", np.uint32), ("density", np.float32), ("pressure", np.float32),
+                              ("phase", np.uint32)])
+assert SLAB_RECORD_DTYPE.itemsize == SLAB_RECORD_BYTES
+
+
+def records_from_aos(aos: np.ndarray, ids: np.ndarray) -> np.ndarray:
+    """72-byte AoS rows (+ global ids) -> slab records."""
+    aos = np.asarray(aos, dtype=np.float32).reshape(-1, PARTICLE_FLOATS)
+    r = np.zeros(aos.shape[0], dtype=SLAB_RECORD_DTYPE)
+    r["pos"], r["vel"], r["acc"] = aos[:, 0:3], aos[:, 3:6], aos[:, 6:9]
+    r["density"], r["pressure"], r["restDensity"] = aos[:, 9], aos[:, 10], aos[:, 11]
+    r["viscosity"], r["mass"] = aos[:, 12], aos[:, 13]
+    r["id"] = ids
+    return r
+
+
+def aos_from_records(r: np.ndarray) -> np.ndarray:
+    """slab records -> 72-byte AoS rows (colour zero), in the records' order."""
+    aos = np.zeros((r.shape[0], PARTICLE_FLOATS), dtype=np.float32)
+    aos[:, 0:3], aos[:, 3:6], aos[:, 6:9] = r["pos"], r["vel"], r["acc"]
+    aos[:, 9], aos[:, 10], aos[:, 11] = r["density"], r["pressure"], r["restDensity"]
+    aos[:, 12], aos[:, 13] = r["viscosity"], r["mass"]
+    return aos

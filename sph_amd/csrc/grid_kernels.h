@@ -28,8 +28,9 @@ __global__ __launch_bounds__(kBlock) void k_hash(DevParams P, const float4* __re
     if (s < P.n) {
         float4 p = posM[s];
         int3 c = cell_unclamped(P, p.x, p.y, p.z);
-        oog = c.x < 0 || c.x >= P.rx || c.y < 0 || c.y >= P.ry || c.z < 0 || c.z >= P.rz;
-        int x = min(max(c.x, 0), P.rx - 1);
+        oog = c.x < 0 || c.x >= P.rxg || c.y < 0 || c.y >= P.ry || c.z < 0 || c.z >= P.rz;
+        int x = min(max(c.x, 0), P.rxg - 1) - P.xoff;   // global clamp (compute:126), then local plane
+        x = min(max(x, 0), P.rx - 1);                    // memory safety only: a slab never holds such a particle
         int y = min(max(c.y, 0), P.ry - 1);
         int z = min(max(c.z, 0), P.rz - 1);
         keys[s] = (uint32_t)(x + y * P.rx + z * P.rx * P.ry);

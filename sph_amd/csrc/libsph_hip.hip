@@ -13,7 +13,7 @@
 #include <string>
 #include <vector>
 
-#include "physics_kernels.h"
+#include "slab_kernels.h"
 
 using namespace sph;
 
@@ -65,6 +65,13 @@ struct sph_ctx {
     bool gridValid = false;
 
     int* counters = nullptr;          // SPH_CTR_COUNT ints on the device
+
+    // slab decomposition (multi-GPU)
+    bool slab = false;
+    int rxGlobal = 0, xOffset = 0, ownLoG = 0, ownHiG = 0;   // global plane coordinates
+    int* slabCounts = nullptr;        // 4 ints on the device (message / rebuild counters)
+    SlabRecord* recStage = nullptr;   // device staging for slab upload / download
+    size_t recStageCap = 0;
     float* aosStage = nullptr;        // device AoS staging (n * 72 B)
     void* pinned = nullptr;           // pinned host staging
     size_t pinnedBytes = 0;
@@ -127,7 +134,8 @@ void freeParticles(sph_ctx* c) {
         devFree(c->keys[k]); devFree(c->vals[k]);
     }
     devFree(c->color); devFree(c->phaseOfId); devFree(c->sid); devFree(c->perm2);
-    devFree(c->blockHist); devFree(c->aosStage);
+    devFree(c->blockHist); devFree(c->aosStage); devFree(c->recStage);
+    c->recStageCap = 0;
     if (c->pinned) (void)hipHostFree(c->pinned);
     c->pinned = nullptr; c->pinnedBytes = 0;
     c->capacity = 0; c->n = 0; c->blockHistElems = 0;
@@ -164,7 +172,12 @@ void deriveParams(sph_ctx* c) {
         d.boundsSize[k] = q.boundsSize[k];
         d.minBound[k] = q.minBound[k];
     }
-    d.rx = q.gridResolutionX; d.ry = q.gridResolutionY; d.rz = q.gridResolutionZ;
+    d.rx = c->slab ? c->rx : q.gridResolutionX;
+    d.ry = q.gridResolutionY; d.rz = q.gridResolutionZ;
+    d.rxg = q.gridResolutionX;
+    d.xoff = c->slab ? c->xOffset : 0;
+    d.ownLo = c->slab ? c->ownLoG - c->xOffset : 0;
+    d.ownHi = c->slab ? c->ownHiG - c->xOffset : d.rx;
     d.cap = q.maxParticlesPerCell;
     d.cellSize = q.cellSize;
     for (int k = 0; k < 12; k++) { d.M[k] = q.boundaryMatrix[k]; d.Minv[k] = q.boundaryInvMatrix[k]; }
@@ -183,10 +196,20 @@ int checkReady(sph_ctx* c, bool needGrid) {
     if (c->n <= 0) return fail(c, SPH_E_STATE, "no particles allocated");
     if (!c->haveParams) return fail(c, SPH_E_STATE, "sph_set_params not called");
     if (c->cells <= 0) return fail(c, SPH_E_STATE, "sph_resize_grid not called");
+    deriveParams(c);   // picks up slab / grid changes made after sph_set_params
     if (c->dp.rx != c->rx || c->dp.ry != c->ry || c->dp.rz != c->rz || c->dp.cap != c->cap)
         return fail(c, SPH_E_STATE, "params grid (%d,%d,%d,cap %d) != allocated grid (%d,%d,%d,cap %d)", c->dp.rx,
                     c->dp.ry, c->dp.rz, c->dp.cap, c->rx, c->ry, c->rz, c->cap);
-    if (c->dp.n != c->n) return fail(c, SPH_E_STATE, "params particleCount %d != allocated %d", c->dp.n, c->n);
+    if (c->slab) {
+        if (c->dp.rxg != c->rxGlobal)
+            return fail(c, SPH_E_STATE, "params gridResolutionX %d != slab global resolution %d", c->dp.rxg, c->rxGlobal);
+        if (c->xOffset < 0 || c->xOffset + c->rx > c->rxGlobal || c->ownLoG < c->xOffset || c->ownHiG > c->xOffset + c->rx)
+            return fail(c, SPH_E_STATE, "slab planes [%d,%d) own [%d,%d) do not fit the local grid of %d planes at %d",
+                        c->xOffset, c->xOffset + c->rx, c->ownLoG, c->ownHiG, c->rx, c->xOffset);
+    } else if (c->prm.particleCount != c->n) {
+        return fail(c, SPH_E_STATE, "params particleCount %d != allocated %d", c->prm.particleCount, c->n);
+    }
+    c->dp.n = c->n;
     if (!(c->dp.cellSize > 0.0f)) return fail(c, SPH_E_INVALID, "cellSize must be > 0");
     if (needGrid && !c->gridValid) return fail(c, SPH_E_STATE, "grid not built (dispatch CS_BuildGrid first)");
     return SPH_OK;
@@ -209,7 +232,7 @@ int harvestSlot(sph_ctx* c, int slot) {
 }
 
 int applyPhaseTable(sph_ctx* c) {
-    if (!c->staticDirty) return SPH_OK;
+    if (!c->staticDirty || c->slab) return SPH_OK;   // slab records carry their static properties
     if (c->phaseTable.empty() || !c->havePhaseIds) { c->staticDirty = false; return SPH_OK; }
     hipLaunchKernelGGL(k_apply_phase_table, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->n,
                        StateSet{c->set[c->cur].posM, c->set[c->velCur].velV, c->set[c->cur].acc,
@@ -241,7 +264,7 @@ int buildGrid(sph_ctx* c) {
     const int nb = blocksFor(n);
     int rc = clearGrid(c);
     if (rc) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->counters + SPH_CTR_BIN_OVERFLOW, 0, 2 * sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->counters + SPH_CTR_BIN_OVERFLOW, 0, 3 * sizeof(int), c->stream));
     StateSet src = curSet(c);
     hipLaunchKernelGGL(k_hash, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, src.posM, c->keys[0], c->counters);
     CHECK_LAUNCH(c);
@@ -290,6 +313,7 @@ int buildGrid(sph_ctx* c) {
 
 int dispatchKernel(sph_ctx* c, int id) {
     const int n = c->n;
+    c->dp.n = n;
     const int nb = blocksFor(n);
     StateSet s = curSet(c);
     switch (id) {
@@ -305,6 +329,9 @@ int dispatchKernel(sph_ctx* c, int id) {
                                s.rhoP, c->cellCum, c->counters);
             hipLaunchKernelGGL(k_density_pressure, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.rho0, s.rhoP,
                                c->cellStart, c->cellEnd, c->counters);
+            if (c->slab)
+                hipLaunchKernelGGL(k_slab_plane_shift, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, c->sortedKeys,
+                                   c->counters);
             break;
         case SPH_K_FORCE_XSPH: {
             float4* velOut = c->set[1 - c->velCur].velV;
@@ -322,7 +349,8 @@ int dispatchKernel(sph_ctx* c, int id) {
             hipLaunchKernelGGL(k_full_step, dim3(nb), dim3(kBlock), 0, c->stream, n, c->dp.dt, s.velV, s.acc);
             break;
         case SPH_K_BOUND_OBS:
-            hipLaunchKernelGGL(k_bound_obs, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, c->counters);
+            hipLaunchKernelGGL(k_bound_obs, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, c->counters,
+                               c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr);
             break;
         case SPH_K_VELOCITY_DAMPING:
             hipLaunchKernelGGL(k_velocity_damping, dim3(nb), dim3(kBlock), 0, c->stream, n, s.velV);
@@ -359,6 +387,7 @@ int sph_create(sph_ctx** out, int device_id) {
         for (int k = 0; k < kNumEvents; k++) (void)hipEventCreate(&c->ev[r][k]);
     if (hipMalloc((void**)&c->counters, SPH_CTR_COUNT * sizeof(int)) != hipSuccess ||
         hipMalloc((void**)&c->digitTotal, kRadix * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void**)&c->slabCounts, 4 * sizeof(int)) != hipSuccess ||
         hipMemsetAsync(c->counters, 0, SPH_CTR_COUNT * sizeof(int), c->stream) != hipSuccess) {
         sph_destroy(c);
         return SPH_E_NOMEM;
@@ -375,6 +404,7 @@ int sph_destroy(sph_ctx* c) {
     freeGrid(c);
     devFree(c->counters);
     devFree(c->digitTotal);
+    devFree(c->slabCounts);
     devFree(c->phaseTableDev);
     for (int r = 0; r < kTimingRing; r++)
         for (int k = 0; k < kNumEvents; k++)
@@ -384,39 +414,43 @@ int sph_destroy(sph_ctx* c) {
     return SPH_OK;
 }
 
+static int allocCapacity(sph_ctx* c, int n) {
+    if (n <= c->capacity) return SPH_OK;
+    freeParticles(c);
+    int rc = 0;
+    for (int k = 0; k < 2 && !rc; k++) {
+        rc = devAlloc(c, &c->set[k].posM, n);
+        if (!rc) rc = devAlloc(c, &c->set[k].velV, n);
+        if (!rc) rc = devAlloc(c, &c->set[k].acc, n);
+        if (!rc) rc = devAlloc(c, &c->set[k].rhoP, n);
+        if (!rc) rc = devAlloc(c, &c->set[k].rho0, n);
+        if (!rc) rc = devAlloc(c, &c->set[k].origId, n);
+        if (!rc) rc = devAlloc(c, &c->keys[k], n);
+        if (!rc) rc = devAlloc(c, &c->vals[k], n);
+    }
+    if (!rc) rc = devAlloc(c, &c->color, n);
+    if (!rc) rc = devAlloc(c, &c->phaseOfId, n);
+    if (!rc) rc = devAlloc(c, &c->sid, n);
+    if (!rc) rc = devAlloc(c, &c->perm2, n);
+    if (!rc) rc = devAlloc(c, &c->aosStage, (size_t)n * SPH_PARTICLE_FLOATS);
+    c->blockHistElems = (size_t)kRadix * ((n + kSortTile - 1) / kSortTile);
+    if (!rc) rc = devAlloc(c, &c->blockHist, c->blockHistElems);
+    if (rc) { freeParticles(c); return rc; }
+    c->capacity = n;
+    return SPH_OK;
+}
+
 int sph_alloc_particles(sph_ctx* c, int n) {
     if (!c) return SPH_E_INVALID;
     if (n <= 0) return fail(c, SPH_E_INVALID, "particle count must be > 0 (got %d)", n);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (n > c->capacity) {
-        freeParticles(c);
-        int rc = 0;
-        for (int k = 0; k < 2 && !rc; k++) {
-            rc = devAlloc(c, &c->set[k].posM, n);
-            if (!rc) rc = devAlloc(c, &c->set[k].velV, n);
-            if (!rc) rc = devAlloc(c, &c->set[k].acc, n);
-            if (!rc) rc = devAlloc(c, &c->set[k].rhoP, n);
-            if (!rc) rc = devAlloc(c, &c->set[k].rho0, n);
-            if (!rc) rc = devAlloc(c, &c->set[k].origId, n);
-            if (!rc) rc = devAlloc(c, &c->keys[k], n);
-            if (!rc) rc = devAlloc(c, &c->vals[k], n);
-        }
-        if (!rc) rc = devAlloc(c, &c->color, n);
-        if (!rc) rc = devAlloc(c, &c->phaseOfId, n);
-        if (!rc) rc = devAlloc(c, &c->sid, n);
-        if (!rc) rc = devAlloc(c, &c->perm2, n);
-        if (!rc) rc = devAlloc(c, &c->aosStage, (size_t)n * SPH_PARTICLE_FLOATS);
-        c->blockHistElems = (size_t)kRadix * ((n + kSortTile - 1) / kSortTile);
-        if (!rc) rc = devAlloc(c, &c->blockHist, c->blockHistElems);
-        if (rc) { freeParticles(c); return rc; }
-        c->capacity = n;
-    }
+    int rc = allocCapacity(c, n);
+    if (rc) return rc;
     c->n = n;
     c->cur = 0; c->velCur = 0;
     c->gridValid = false;
     c->havePhaseIds = false;
-    c->dp.n = c->haveParams ? c->prm.particleCount : 0;
     // a fresh ComputeBuffer is zero-filled; give ids so download before upload is well defined
     HIP_TRY(c, hipMemsetAsync(c->aosStage, 0, (size_t)n * SPH_PARTICLE_BYTES, c->stream));
     hipLaunchKernelGGL(k_import_aos, dim3(blocksFor(n)), dim3(kBlock), 0, c->stream, n, c->aosStage, c->set[0], c->color);
@@ -426,6 +460,7 @@ int sph_alloc_particles(sph_ctx* c, int n) {
 
 int sph_upload_particles(sph_ctx* c, const void* aos72, int n) {
     if (!c) return SPH_E_INVALID;
+    if (c->slab) return fail(c, SPH_E_STATE, "id-ordered AoS transfer is not available in slab mode (use sph_slab_upload)");
     if (!aos72) return fail(c, SPH_E_INVALID, "null particle array");
     if (n != c->n || n <= 0) return fail(c, SPH_E_INVALID, "upload count %d != allocated %d", n, c->n);
     HIP_TRY(c, hipSetDevice(c->device));
@@ -445,6 +480,7 @@ int sph_upload_particles(sph_ctx* c, const void* aos72, int n) {
 
 int sph_download_particles(sph_ctx* c, void* aos72, int n) {
     if (!c) return SPH_E_INVALID;
+    if (c->slab) return fail(c, SPH_E_STATE, "id-ordered AoS transfer is not available in slab mode (use sph_slab_download)");
     if (!aos72) return fail(c, SPH_E_INVALID, "null particle array");
     if (n != c->n || n <= 0) return fail(c, SPH_E_INVALID, "download count %d != allocated %d", n, c->n);
     HIP_TRY(c, hipSetDevice(c->device));
@@ -493,7 +529,6 @@ int sph_set_params(sph_ctx* c, const sph_params* p) {
     c->prm = *p;
     c->haveParams = true;
     deriveParams(c);
-    c->dp.n = p->particleCount;
     return SPH_OK;
 }
 
@@ -621,6 +656,7 @@ int sph_download_grid(sph_ctx* c, int32_t* cell_start, int32_t* cell_end, int32_
                       uint32_t* cell_of_particle) {
     if (!c) return SPH_E_INVALID;
     if (!c->gridValid) return fail(c, SPH_E_STATE, "grid not built");
+    if (c->slab && cell_of_particle) return fail(c, SPH_E_STATE, "cell_of_particle is indexed by id: not available in slab mode");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t cb = sizeof(int) * (size_t)c->cells, nb = sizeof(int) * (size_t)c->n;
     if (cell_start) HIP_TRY(c, hipMemcpyAsync(cell_start, c->cellStart, cb, hipMemcpyDeviceToHost, c->stream));
@@ -642,6 +678,7 @@ int sph_download_neighbors(sph_ctx* c, int32_t* counts, int32_t* lists, int max_
     if (!counts || max_neighbors < 0) return fail(c, SPH_E_INVALID, "bad neighbour export arguments");
     int rc = checkReady(c, true);
     if (rc) return rc;
+    if (c->slab) return fail(c, SPH_E_STATE, "neighbour export is indexed by id: not available in slab mode");
     HIP_TRY(c, hipSetDevice(c->device));
     int *dCounts = nullptr, *dLists = nullptr;
     const size_t lb = sizeof(int) * (size_t)c->n * (size_t)max_neighbors;
@@ -711,6 +748,158 @@ int sph_device_pointer(sph_ctx* c, const char* name, void** ptr, uint64_t* bytes
 int sph_get_stream(sph_ctx* c, void** stream) {
     if (!c || !stream) return SPH_E_INVALID;
     *stream = (void*)c->stream;
+    return SPH_OK;
+}
+
+// ---- slab decomposition -------------------------------------------------------------------------------
+int sph_slab_configure(sph_ctx* c, int rx_global, int x_offset, int own_lo, int own_hi) {
+    if (!c) return SPH_E_INVALID;
+    if (rx_global <= 0) { c->slab = false; c->gridValid = false; return SPH_OK; }
+    if (x_offset < 0 || own_lo < x_offset || own_hi < own_lo || own_hi > rx_global)
+        return fail(c, SPH_E_INVALID, "bad slab: global %d, offset %d, own [%d,%d)", rx_global, x_offset, own_lo, own_hi);
+    c->slab = true;
+    c->rxGlobal = rx_global; c->xOffset = x_offset; c->ownLoG = own_lo; c->ownHiG = own_hi;
+    c->gridValid = false;
+    return SPH_OK;
+}
+
+int sph_slab_reserve(sph_ctx* c, int capacity) {
+    if (!c) return SPH_E_INVALID;
+    if (capacity <= 0) return fail(c, SPH_E_INVALID, "capacity must be > 0");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (capacity > c->capacity) {
+        if (c->n > 0) return fail(c, SPH_E_STATE, "sph_slab_reserve cannot grow a populated slab (reserve before upload)");
+        int rc = allocCapacity(c, capacity);
+        if (rc) return rc;
+        c->n = 0; c->cur = 0; c->velCur = 0; c->gridValid = false;
+    }
+    return SPH_OK;
+}
+
+static int ensureRecStage(sph_ctx* c, size_t n) {
+    if (n <= c->recStageCap) return SPH_OK;
+    devFree(c->recStage);
+    c->recStageCap = 0;
+    int rc = devAlloc(c, &c->recStage, n);
+    if (rc) return rc;
+    c->recStageCap = n;
+    return SPH_OK;
+}
+
+int sph_slab_upload(sph_ctx* c, const sph_slab_record* records, int n) {
+    if (!c) return SPH_E_INVALID;
+    if (!c->slab) return fail(c, SPH_E_STATE, "sph_slab_configure first");
+    if (n < 0 || (n > 0 && !records)) return fail(c, SPH_E_INVALID, "bad records");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n > c->capacity) {
+        c->n = 0;
+        int rc = allocCapacity(c, n);
+        if (rc) return rc;
+    }
+    c->cur = 0; c->velCur = 0; c->gridValid = false;
+    c->n = n;
+    if (n == 0) return SPH_OK;
+    int rc = ensureRecStage(c, (size_t)n);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpy(c->recStage, records, sizeof(SlabRecord) * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_slab_import, dim3(blocksFor(n)), dim3(kBlock), 0, c->stream, n, c->recStage, c->set[0]);
+    CHECK_LAUNCH(c);
+    return SPH_OK;
+}
+
+int sph_slab_download(sph_ctx* c, sph_slab_record* records, int max_records, int owned_only, int* n_out) {
+    if (!c) return SPH_E_INVALID;
+    if (!c->slab) return fail(c, SPH_E_STATE, "sph_slab_configure first");
+    if (!n_out || max_records < 0 || (max_records > 0 && !records)) return fail(c, SPH_E_INVALID, "bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    *n_out = 0;
+    if (c->n == 0) return SPH_OK;
+    if (c->haveParams) deriveParams(c);
+    c->dp.n = c->n;
+    int rc = ensureRecStage(c, (size_t)c->n);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->slabCounts, 0, 4 * sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_slab_export, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->dp, curSet(c),
+                       c->gridValid ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr, owned_only, c->recStage,
+                       c->n, c->slabCounts);
+    CHECK_LAUNCH(c);
+    int cnt = 0;
+    HIP_TRY(c, hipMemcpyAsync(&cnt, c->slabCounts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (cnt > max_records) return fail(c, SPH_E_INVALID, "%d records do not fit %d", cnt, max_records);
+    if (cnt > 0) HIP_TRY(c, hipMemcpy(records, c->recStage, sizeof(SlabRecord) * (size_t)cnt, hipMemcpyDeviceToHost));
+    *n_out = cnt;
+    return SPH_OK;
+}
+
+int sph_slab_pack(sph_ctx* c, int left_below, int right_from, void* dev_left, int cap_left, void* dev_right,
+                  int cap_right, int* n_left, int* n_right) {
+    if (!c) return SPH_E_INVALID;
+    if (!c->slab || !c->haveParams) return fail(c, SPH_E_STATE, "sph_slab_configure and sph_set_params first");
+    if (!n_left || !n_right || cap_left < 0 || cap_right < 0 || (cap_left > 0 && !dev_left) || (cap_right > 0 && !dev_right))
+        return fail(c, SPH_E_INVALID, "bad message buffers");
+    HIP_TRY(c, hipSetDevice(c->device));
+    deriveParams(c);
+    c->dp.n = c->n;
+    *n_left = *n_right = 0;
+    if (c->n == 0) return SPH_OK;
+    HIP_TRY(c, hipMemsetAsync(c->slabCounts, 0, 4 * sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_slab_pack, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->dp, curSet(c),
+                       c->gridValid ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr, left_below, right_from,
+                       (SlabRecord*)dev_left, cap_left, (SlabRecord*)dev_right, cap_right, c->slabCounts);
+    CHECK_LAUNCH(c);
+    int cnt[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(cnt, c->slabCounts, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n_left = cnt[0];
+    *n_right = cnt[1];
+    if (cnt[0] > cap_left || cnt[1] > cap_right)
+        return fail(c, SPH_E_NOMEM, "slab message overflow: %d/%d left, %d/%d right records", cnt[0], cap_left, cnt[1], cap_right);
+    return SPH_OK;
+}
+
+int sph_slab_rebuild(sph_ctx* c, int keep_lo, int keep_hi, const void* dev_from_left, int n_from_left,
+                     const void* dev_from_right, int n_from_right, int* n_local) {
+    if (!c) return SPH_E_INVALID;
+    if (!c->slab || !c->haveParams) return fail(c, SPH_E_STATE, "sph_slab_configure and sph_set_params first");
+    if (!n_local || n_from_left < 0 || n_from_right < 0) return fail(c, SPH_E_INVALID, "bad arguments");
+    if (c->capacity <= 0) return fail(c, SPH_E_STATE, "sph_slab_reserve first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    deriveParams(c);
+    c->dp.n = c->n;
+    StateSet src = curSet(c);
+    StateSet dst = c->set[1 - c->cur];
+    dst.velV = c->set[1 - c->velCur].velV;
+    HIP_TRY(c, hipMemsetAsync(c->slabCounts, 0, 4 * sizeof(int), c->stream));
+    if (c->n > 0)
+        hipLaunchKernelGGL(k_slab_keep, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->dp, src,
+                           c->gridValid ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr, keep_lo, keep_hi, dst,
+                           c->capacity, c->slabCounts);
+    if (n_from_left > 0)
+        hipLaunchKernelGGL(k_slab_append, dim3(blocksFor(n_from_left)), dim3(kBlock), 0, c->stream, c->dp,
+                           (const SlabRecord*)dev_from_left, n_from_left, keep_lo, keep_hi, dst, c->capacity, c->slabCounts);
+    if (n_from_right > 0)
+        hipLaunchKernelGGL(k_slab_append, dim3(blocksFor(n_from_right)), dim3(kBlock), 0, c->stream, c->dp,
+                           (const SlabRecord*)dev_from_right, n_from_right, keep_lo, keep_hi, dst, c->capacity,
+                           c->slabCounts);
+    CHECK_LAUNCH(c);
+    int cnt = 0;
+    HIP_TRY(c, hipMemcpyAsync(&cnt, c->slabCounts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (cnt > c->capacity) return fail(c, SPH_E_NOMEM, "slab population %d exceeds the reserved capacity %d", cnt, c->capacity);
+    c->cur = 1 - c->cur;
+    c->velCur = 1 - c->velCur;
+    c->n = cnt;
+    c->gridValid = false;
+    *n_local = cnt;
+    return SPH_OK;
+}
+
+int sph_particle_count(sph_ctx* c, int* n) {
+    if (!c || !n) return SPH_E_INVALID;
+    *n = c->n;
     return SPH_OK;
 }
 

@@ -27,14 +27,16 @@ __device__ __forceinline__ void for_each_candidate(const DevParams& P, const int
     int3 c = cell_unclamped(P, px, py, pz);
     // cells further than 1 outside the grid have no in-range neighbour cell; clamping them to
     // [-2, r+1] keeps that and avoids signed overflow on saturated coordinates
-    c.x = min(max(c.x, -2), P.rx + 1);
+    c.x = min(max(c.x, -2), P.rxg + 1);
     c.y = min(max(c.y, -2), P.ry + 1);
     c.z = min(max(c.z, -2), P.rz + 1);
     for (int z = c.z - 1; z <= c.z + 1; z++) {
         if (z < 0 || z >= P.rz) continue;
         for (int y = c.y - 1; y <= c.y + 1; y++) {
             if (y < 0 || y >= P.ry) continue;
-            for (int x = c.x - 1; x <= c.x + 1; x++) {
+            for (int xg = c.x - 1; xg <= c.x + 1; xg++) {
+                if (xg < 0 || xg >= P.rxg) continue;
+                const int x = xg - P.xoff;               // local plane; outside only for ghost targets
                 if (x < 0 || x >= P.rx) continue;
                 const int ci = x + y * P.rx + z * P.rx * P.ry;
                 const int a = cellStart[ci];
@@ -167,7 +169,7 @@ struct RowRange { int a, e; };
 
 __device__ __forceinline__ int3 search_cell(const DevParams& P, float px, float py, float pz) {
     int3 c = cell_unclamped(P, px, py, pz);
-    c.x = min(max(c.x, -2), P.rx + 1);
+    c.x = min(max(c.x, -2), P.rxg + 1);
     c.y = min(max(c.y, -2), P.ry + 1);
     c.z = min(max(c.z, -2), P.rz + 1);
     return c;
@@ -176,7 +178,8 @@ __device__ __forceinline__ int3 search_cell(const DevParams& P, float px, float 
 __device__ __forceinline__ RowRange row_range(const DevParams& P, const int* __restrict__ cellCum, int3 c, int dy,
                                               int dz, bool live) {
     const int y = c.y + dy, z = c.z + dz;
-    const int xlo = max(c.x - 1, 0), xhi = min(c.x + 1, P.rx - 1);
+    // global x range (compute:166), then the part of it this slab holds
+    const int xlo = max(max(c.x - 1, 0) - P.xoff, 0), xhi = min(min(c.x + 1, P.rxg - 1) - P.xoff, P.rx - 1);
     RowRange r{0, 0};
     if (live && y >= 0 && y < P.ry && z >= 0 && z < P.rz && xlo <= xhi) {
         const int base = y * P.rx + z * P.rx * P.ry;
@@ -373,7 +376,8 @@ __device__ __forceinline__ float dot3f(float ax, float ay, float az, float bx, f
 // CS_BoundObs (compute:340-486).  The per-collision InterlockedAdd (compute:418) becomes one
 // wave ballot + popcount and a single atomic per wave.
 __global__ __launch_bounds__(kBlock) void k_bound_obs(DevParams P, float4* __restrict__ posM,
-                                                      float4* __restrict__ velV, int* __restrict__ counters) {
+                                                      float4* __restrict__ velV, int* __restrict__ counters,
+                                                      const uint32_t* __restrict__ sortedKeys) {
     int s = blockIdx.x * kBlock + threadIdx.x;
     bool collided = false;
     if (s < P.n) {
@@ -454,6 +458,10 @@ __global__ __launch_bounds__(kBlock) void k_bound_obs(DevParams P, float4* __res
         }
         posM[s] = p;
         velV[s] = v;
+        if (sortedKeys) {   // slab mode: ghost copies are counted by their owner
+            const int plane = (int)(sortedKeys[s] % (uint32_t)P.rx);
+            collided = collided && plane >= P.ownLo && plane < P.ownHi;
+        }
     }
     const unsigned long long m = __ballot(collided);
     if (m && (threadIdx.x & 63) == 0) atomicAdd(&counters[SPH_CTR_COLLISIONS], __popcll(m));

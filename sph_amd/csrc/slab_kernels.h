@@ -1,0 +1,159 @@
+// slab_kernels.h -- multi-GPU slab decomposition support (no counterpart in the reference, which is
+// single-GPU).  The domain is cut into x-slabs of whole cell planes, one
+// per GPU.  A rank's local particle set = the particles it owns + read-only ghost copies of the
+// planes next to its slab.  Once per frame each rank sends ONE message to each slab neighbour
+// (its particles near that face: emigrants and ghosts alike, the receiver tells them apart by
+// plane) and rebuilds its local set; the frame itself then runs with no further communication.
+#pragma once
+#include "physics_kernels.h"
+
+namespace sph {
+
+struct SlabRecord {      // == struct sph_slab_record (64 B)
+    float4 posM;
+    float4 velV;
+    float4 accR;         // ax, ay, az, restDensity
+    uint32_t id;         // global particle id
+    float density, pressure;
+    uint32_t phase;
+};
+static_assert(sizeof(SlabRecord) == 64, "64-byte slab record");
+
+// global cell plane of a position, clamped like CS_BuildGrid clamps it (compute:125-126)
+__device__ __forceinline__ int global_plane(const DevParams& P, float x) {
+    const int c = (int)floorf((x - P.minBound[0]) / P.cellSize);
+    return min(max(c, 0), P.rxg - 1);
+}
+
+// owned at the last grid build?  (all particles are "owned" before the first build)
+__device__ __forceinline__ bool was_owned(const DevParams& P, const uint32_t* __restrict__ sortedKeys, int s) {
+    if (!sortedKeys) return true;
+    const int plane = (int)(sortedKeys[s] % (uint32_t)P.rx);
+    return plane >= P.ownLo && plane < P.ownHi;
+}
+
+// wave-aggregated append: one atomic per wave, slot = base + rank among the appending lanes
+__device__ __forceinline__ int wave_append(bool pred, int* counter) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0ull) return -1;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader);
+    return pred ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+
+__device__ __forceinline__ SlabRecord make_record(const StateSet& st, int s) {
+    SlabRecord r;
+    r.posM = st.posM[s];
+    r.velV = st.velV[s];
+    const float4 a = st.acc[s];
+    r.accR = make_float4(a.x, a.y, a.z, st.rho0[s]);
+    const float2 d = st.rhoP[s];
+    r.id = st.origId[s];
+    r.density = d.x;
+    r.pressure = d.y;
+    r.phase = 0u;
+    return r;
+}
+
+__device__ __forceinline__ void store_record(const StateSet& st, int k, const SlabRecord& r) {
+    st.posM[k] = r.posM;
+    st.velV[k] = r.velV;
+    st.acc[k] = make_float4(r.accR.x, r.accR.y, r.accR.z, 0.f);
+    st.rhoP[k] = make_float2(r.density, r.pressure);
+    st.rho0[k] = r.accR.w;
+    st.origId[k] = r.id;
+}
+
+// Messages to the slab neighbours: previously-owned particles whose CURRENT plane is below
+// `leftBelow` (-> left message) or at/above `rightFrom` (-> right message).  counts[0..1].
+__global__ __launch_bounds__(kBlock) void k_slab_pack(DevParams P, StateSet st, const uint32_t* __restrict__ sortedKeys,
+                                                      int leftBelow, int rightFrom, SlabRecord* __restrict__ left,
+                                                      int capLeft, SlabRecord* __restrict__ right, int capRight,
+                                                      int* __restrict__ counts) {
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    bool toL = false, toR = false;
+    if (s < P.n && was_owned(P, sortedKeys, s)) {
+        const int g = global_plane(P, st.posM[s].x);
+        toL = g < leftBelow;
+        toR = g >= rightFrom;
+    }
+    const int il = wave_append(toL, &counts[0]);
+    const int ir = wave_append(toR, &counts[1]);
+    if (toL && il < capLeft) left[il] = make_record(st, s);
+    if (toR && ir < capRight) right[ir] = make_record(st, s);
+}
+
+// Previously-owned particles that stay local (as owned or as ghost): current plane in [keepLo, keepHi).
+__global__ __launch_bounds__(kBlock) void k_slab_keep(DevParams P, StateSet src, const uint32_t* __restrict__ sortedKeys,
+                                                      int keepLo, int keepHi, StateSet dst, int capacity,
+                                                      int* __restrict__ count) {
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    bool keep = false;
+    if (s < P.n && was_owned(P, sortedKeys, s)) {
+        const int g = global_plane(P, src.posM[s].x);
+        keep = g >= keepLo && g < keepHi;
+    }
+    const int k = wave_append(keep, count);
+    if (keep && k < capacity) {
+        dst.posM[k] = src.posM[s];
+        dst.velV[k] = src.velV[s];
+        dst.acc[k] = src.acc[s];
+        dst.rhoP[k] = src.rhoP[s];
+        dst.rho0[k] = src.rho0[s];
+        dst.origId[k] = src.origId[s];
+    }
+}
+
+// Received records whose plane is in [keepLo, keepHi) join the local set.
+__global__ __launch_bounds__(kBlock) void k_slab_append(DevParams P, const SlabRecord* __restrict__ rec, int nrec,
+                                                        int keepLo, int keepHi, StateSet dst, int capacity,
+                                                        int* __restrict__ count) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    bool keep = false;
+    SlabRecord r;
+    if (i < nrec) {
+        r = rec[i];
+        const int g = global_plane(P, r.posM.x);
+        keep = g >= keepLo && g < keepHi;
+    }
+    const int k = wave_append(keep, count);
+    if (keep && k < capacity) store_record(dst, k, r);
+}
+
+// Export of the local set as records (owned only, or everything), compacted.
+__global__ __launch_bounds__(kBlock) void k_slab_export(DevParams P, StateSet st, const uint32_t* __restrict__ sortedKeys,
+                                                        int ownedOnly, SlabRecord* __restrict__ out, int cap,
+                                                        int* __restrict__ count) {
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    const bool take = s < P.n && (!ownedOnly || was_owned(P, sortedKeys, s));
+    const int k = wave_append(take, count);
+    if (take && k < cap) out[k] = make_record(st, s);
+}
+
+__global__ __launch_bounds__(kBlock) void k_slab_import(int n, const SlabRecord* __restrict__ rec, StateSet dst) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) store_record(dst, i, rec[i]);
+}
+
+// max over particles of |current search plane - plane binned at the last grid build|: the halo is
+// wide enough iff ghostPlanes >= 2 * (1 + this)   (see sph_amd/slab.py)
+__global__ __launch_bounds__(kBlock) void k_slab_plane_shift(DevParams P, const float4* __restrict__ posM,
+                                                             const uint32_t* __restrict__ sortedKeys,
+                                                             int* __restrict__ counters) {
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    int shift = 0;
+    if (s < P.n) {
+        int c = (int)floorf((posM[s].x - P.minBound[0]) / P.cellSize);
+        c = min(max(c, -2), P.rxg + 1);
+        const int binned = (int)(sortedKeys[s] % (uint32_t)P.rx) + P.xoff;
+        shift = abs(c - binned);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) shift = max(shift, __shfl_xor(shift, o));
+    if ((threadIdx.x & 63) == 0 && shift > 0) atomicMax(&counters[SPH_CTR_MAX_PLANE_SHIFT], shift);
+}
+
+}  // namespace sph

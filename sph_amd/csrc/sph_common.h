@@ -20,7 +20,10 @@ struct DevParams {
     float obstacleRadius;
     float obstaclePos[3];
     float boundsCenter[3], boundsSize[3];
-    int   rx, ry, rz, cap;
+    int   rx, ry, rz, cap;   // LOCAL grid (what the cell tables index); rx == rxg on one GPU
+    // slab decomposition: the local grid is planes [xoff, xoff + rx) of a global grid rxg wide;
+    // planes [ownLo, ownHi) (local coordinates) are owned, the rest are ghost planes
+    int   rxg, xoff, ownLo, ownHi;
     float cellSize;
     float minBound[3];
     float M[12];      // rows 0..2 of _BoundaryMatrix    (row 3 is never read: compute:351, 396 take .xyz)

@@ -247,7 +247,9 @@ class SPH:
     # ---------------------------------------------------------------- Start, SPH.cs:112-171
     def Start(self):
         self.particleCount = sum(sb.particleCount for sb in self.spawnBoxes)      # SPH.cs:124-128
-        self.CreateParticles()                                                    # SPH.cs:134
+        grid_first = getattr(self.engine, "grid_first", False)
+        if not grid_first:
+            self.CreateParticles()                                                # SPH.cs:134
         if self.boundaryCube is None:                                             # SPH.cs:137-148
             half = self.boundsSize * f32(0.5)
             self.gridMin = (self.boundsCenter - half).astype(np.float32)
@@ -258,6 +260,11 @@ class SPH:
             self.UpdateGridParametersFromBoundary()                               # SPH.cs:151
             self.lastBoundaryCubePosition = self.boundaryCube.position.copy()
             self.lastBoundaryCubeRotation = self.boundaryCube.rotation.copy()
+        if grid_first:
+            # slab engines filter the spawned rows by plane as they arrive, so they must know the
+            # grid first; the order of these two host steps does not change any result
+            self.engine.preview_grid(float(self.gridMin[0]), float(self.cellSize))
+            self.CreateParticles()
         self.engine.reset_counter(abi.CTR_COLLISIONS)                             # SPH.cs:158
         self.SetComputeParams()                                                   # SPH.cs:162
 
@@ -297,33 +304,50 @@ class SPH:
         self.engine.destroy()
 
     # ---------------------------------------------------------------- SPH.cs:246-282
+    def _spawn_rows(self, bi, sb, first_index, cnt, offset):
+        """Rows offset .. offset+cnt-1 of spawn box bi (global ids first_index+offset ..)."""
+        rows = np.zeros((cnt, abi.PARTICLE_FLOATS), dtype=np.float32)
+        halfSpawn = (sb.spawnSize * f32(0.5)).astype(np.float32)
+        u = spawn_uniforms(self.seed, first_index + offset, cnt)
+        # Random.Range(-half, half) -> lerp(-half, +half, u), fp32 (rule O9)
+        r = ((-halfSpawn)[None, :] + u * (halfSpawn - (-halfSpawn))[None, :]).astype(np.float32)
+        rows[:, 0:3] = (sb.SpawnCenter[None, :] + r).astype(np.float32)
+        rows[:, 3:6] = sb.initialVelocity
+        rows[:, 9] = sb.restDensity
+        rows[:, 11] = sb.restDensity
+        rows[:, 12] = sb.viscosity
+        rows[:, 13] = sb.particleMass
+        rows[:, 14:18] = sb.particleColor
+        return rows
+
     def CreateParticles(self):
         n = self.particleCount
+        e = self.engine
+        if getattr(e, "grid_first", False):
+            # slab run: every rank walks the same global id sequence but only materialises the
+            # boxes that can touch its planes, in bounded chunks (counter-based RNG, rule O9)
+            e.alloc_particles(n)
+            index = 0
+            for bi, sb in enumerate(self.spawnBoxes):
+                half_x = float(sb.spawnSize[0]) * 0.5
+                if e.box_may_matter(float(sb.SpawnCenter[0]) - half_x, float(sb.SpawnCenter[0]) + half_x):
+                    for off in range(0, sb.particleCount, 1 << 20):
+                        cnt = min(1 << 20, sb.particleCount - off)
+                        e.add_rows(index + off, self._spawn_rows(bi, sb, index, cnt, off))
+                index += sb.particleCount
+            return
         init = np.zeros((n, abi.PARTICLE_FLOATS), dtype=np.float32)
         self.particleSpawnBoxIndices = np.zeros(n, dtype=np.uint8)
         index = 0
         for bi, sb in enumerate(self.spawnBoxes):
             cnt = sb.particleCount
-            halfSpawn = (sb.spawnSize * f32(0.5)).astype(np.float32)
-            u = spawn_uniforms(self.seed, index, cnt)
-            # Random.Range(-half, half) -> lerp(-half, +half, u), fp32 (rule O9)
-            r = ((-halfSpawn)[None, :] + u * (halfSpawn - (-halfSpawn))[None, :]).astype(np.float32)
-            rows = init[index:index + cnt]
-            rows[:, 0:3] = (sb.SpawnCenter[None, :] + r).astype(np.float32)
-            rows[:, 3:6] = sb.initialVelocity
-            rows[:, 6:9] = 0
-            rows[:, 9] = sb.restDensity
-            rows[:, 10] = 0
-            rows[:, 11] = sb.restDensity
-            rows[:, 12] = sb.viscosity
-            rows[:, 13] = sb.particleMass
-            rows[:, 14:18] = sb.particleColor
+            init[index:index + cnt] = self._spawn_rows(bi, sb, index, cnt, 0)
             self.particleSpawnBoxIndices[index:index + cnt] = bi                  # SPH.cs:276
             index += cnt
-        self.engine.alloc_particles(n)                                            # SPH.cs:249
-        self.engine.upload_particles(init)                                        # SPH.cs:280
-        self.engine.set_phase_table(self._phase_rows())
-        self.engine.set_phase_ids(self.particleSpawnBoxIndices)
+        e.alloc_particles(n)                                                      # SPH.cs:249
+        e.upload_particles(init)                                                  # SPH.cs:280
+        e.set_phase_table(self._phase_rows())
+        e.set_phase_ids(self.particleSpawnBoxIndices)
 
     def _phase_rows(self):
         return [(sb.restDensity, sb.viscosity, sb.particleMass, sb.particleColor) for sb in self.spawnBoxes]

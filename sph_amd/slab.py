@@ -1,0 +1,398 @@
+"""Multi-GPU slab decomposition of the SPH frame step.
+
+The reference is single-GPU; this is new work with no reference counterpart.  One process per
+GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI on MI355X; "gloo" for tests).
+
+Decomposition
+  * the GLOBAL grid (RX x RY x RZ cells) is cut into G slabs of whole cell planes along x
+    (gravity stratifies y, so x keeps slabs balanced); rank r owns planes [x0_r, x1_r);
+  * a rank's local particle set = the particles it owns + ghost copies of `ghost_planes` planes on
+    each side; its local grid is planes [x0 - ghost, x1 + ghost) of the global grid; cell
+    coordinates are still computed against the GLOBAL origin and shifted by an integer plane offset,
+    so the hash is bit-identical to a single-GPU run;
+  * particle ids are global, and the (cell, id) order inside the engine makes every neighbour
+    sum visit the same particles in the same order as a single-GPU run: results are bit-identical
+    for owned particles, whatever G is.
+
+Per frame (before the grid build of SPH.Update, SPH.cs:201-204) each rank sends ONE message to each
+slab neighbour: its owned particles whose current plane lies within `ghost_planes` of that face or
+beyond it.  The receiver keeps what falls into its local plane range: records in its own planes
+are immigrants (now owned), the others are ghosts.  The sender keeps its emigrants as ghosts.  Last
+frame's ghosts are dropped.  The frame then runs with NO further communication: ghosts are advanced
+redundantly (half-step and density are recomputed locally for them from identical inputs, hence
+bit-identical), which needs ghost_planes >= 2 * (1 + max plane shift of a particle during the
+half-step); the engine measures that shift every frame (SPH_CTR_MAX_PLANE_SHIFT) and the driver
+counts violations.  Point-to-point only: each GPU talks to at most two peers over their direct xGMI
+links; there is no collective on the data path.
+
+Limits of this round: static slab boundaries (equal plane counts), static boundary cube,
+subSteps == 1 (a ghost refresh per extra sub-step is not implemented), migration to adjacent slabs
+only (particles conserved is asserted by `count_global`).
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Optional
+
+import numpy as np
+
+from . import abi
+
+REC = abi.SLAB_RECORD_BYTES
+
+
+def slab_ranges(rx_global: int, world: int):
+    """Equal split of the x planes: [(x0, x1)] per rank."""
+    cuts = [(rx_global * r) // world for r in range(world + 1)]
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+# ------------------------------------------------------------------------------------------------
+# ports: how the driver talks to one rank's engine.  Messages are torch uint8 tensors [n, 64].
+# ------------------------------------------------------------------------------------------------
+class DevicePort:
+    """libsph_hip engine; message buffers are torch tensors on the engine's GPU."""
+
+    def __init__(self, engine: abi.Engine, device_index: int, msg_capacity: int):
+        import torch
+        self.torch = torch
+        self.e = engine
+        self.device = torch.device("cuda", device_index)
+        self.cap = int(msg_capacity)
+        self.send_l = torch.empty((self.cap, REC), dtype=torch.uint8, device=self.device)
+        self.send_r = torch.empty((self.cap, REC), dtype=torch.uint8, device=self.device)
+
+    def configure(self, rx_global, x_offset, rx_local, ry, rz, cap, own_lo, own_hi, capacity):
+        self.e.slab_configure(rx_global, x_offset, own_lo, own_hi)
+        self.e.slab_reserve(capacity)
+        self.e.resize_grid(rx_local, ry, rz, cap)
+
+    def upload_owned(self, records):
+        self.e.slab_upload(records)
+
+    def pack(self, left_below, right_from):
+        nl, nr = self.e.slab_pack(left_below, right_from, self.send_l.data_ptr(), self.cap, self.send_r.data_ptr(), self.cap)
+        return self.send_l[:nl], self.send_r[:nr]
+
+    def rebuild(self, keep_lo, keep_hi, from_left, from_right):
+        self.torch.cuda.synchronize(self.device)          # received data is complete
+        pl = from_left.data_ptr() if from_left is not None and from_left.shape[0] else None
+        pr = from_right.data_ptr() if from_right is not None and from_right.shape[0] else None
+        nl = 0 if pl is None else from_left.shape[0]
+        nr = 0 if pr is None else from_right.shape[0]
+        return self.e.slab_rebuild(keep_lo, keep_hi, pl, nl, pr, nr)
+
+    def download_owned(self):
+        return self.e.slab_download(owned_only=True)
+
+    def local_count(self):
+        return self.e.particle_count()
+
+
+# ------------------------------------------------------------------------------------------------
+# communication: neighbour-to-neighbour send/recv of record tensors
+# ------------------------------------------------------------------------------------------------
+class NeighbourComm:
+    def __init__(self, rank: int, world: int, device, backend: Optional[str] = None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.world, self.device = rank, world, device
+        self.backend = backend or dist.get_backend()
+        self.stage_cpu = self.backend == "gloo"
+
+    def _dev(self):
+        return self.torch.device("cpu") if self.stage_cpu else self.device
+
+    def _xfer(self, sends, recvs):
+        ops = []
+        for t, peer in sends:
+            ops.append(self.dist.P2POp(self.dist.isend, t, peer))
+        for t, peer in recvs:
+            ops.append(self.dist.P2POp(self.dist.irecv, t, peer))
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def exchange(self, to_left, to_right):
+        """Send to_left to rank-1 and to_right to rank+1; returns (from_left, from_right)."""
+        torch = self.torch
+        left = self.rank - 1 if self.rank > 0 else None
+        right = self.rank + 1 if self.rank < self.world - 1 else None
+        dev = self._dev()
+        # 1) counts
+        cs_l = torch.tensor([to_left.shape[0]], dtype=torch.int64, device=dev)
+        cs_r = torch.tensor([to_right.shape[0]], dtype=torch.int64, device=dev)
+        cr_l = torch.zeros(1, dtype=torch.int64, device=dev)
+        cr_r = torch.zeros(1, dtype=torch.int64, device=dev)
+        sends, recvs = [], []
+        if left is not None:
+            sends.append((cs_l, left)); recvs.append((cr_l, left))
+        if right is not None:
+            sends.append((cs_r, right)); recvs.append((cr_r, right))
+        self._xfer(sends, recvs)
+        n_from_l, n_from_r = int(cr_l.item()), int(cr_r.item())
+        # 2) payload
+        buf_l = torch.empty((n_from_l, REC), dtype=torch.uint8, device=dev)
+        buf_r = torch.empty((n_from_r, REC), dtype=torch.uint8, device=dev)
+        sl = to_left.to(dev).contiguous() if left is not None else None
+        sr = to_right.to(dev).contiguous() if right is not None else None
+        sends, recvs = [], []
+        if left is not None:
+            if sl.shape[0]:
+                sends.append((sl, left))
+            if n_from_l:
+                recvs.append((buf_l, left))
+        if right is not None:
+            if sr.shape[0]:
+                sends.append((sr, right))
+            if n_from_r:
+                recvs.append((buf_r, right))
+        self._xfer(sends, recvs)
+        if self.stage_cpu and self.device is not None and self.torch.device(self.device).type != "cpu":
+            buf_l, buf_r = buf_l.to(self.device), buf_r.to(self.device)
+        return buf_l, buf_r
+
+    def allreduce_sum(self, value: int) -> int:
+        t = self.torch.tensor([value], dtype=self.torch.int64, device=self._dev())
+        self.dist.all_reduce(t)
+        return int(t.item())
+
+    def allreduce_max(self, value: float) -> float:
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=self._dev())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+# ------------------------------------------------------------------------------------------------
+# the engine-shaped object the host driver (sph_amd.host.SPH) talks to
+# ------------------------------------------------------------------------------------------------
+class SlabEngine:
+    """Stands where sph_amd.abi.Engine stands for host.SPH, for one rank of a slab-decomposed run."""
+
+    def __init__(self, port, comm: NeighbourComm, rank: int, world: int, ghost_planes: int = 8,
+                 capacity_factor: float = 1.6):
+        self.port, self.comm, self.rank, self.world = port, comm, rank, world
+        self.ghost = int(ghost_planes)
+        self.capacity_factor = capacity_factor
+        self.e = port.e
+        self.n_global = 0
+        self.n = 0
+        self.cells = 0
+        self.grid = None
+        self.own = None
+        self._rows = []
+        self._min_x = None
+        self._cell = None
+        self.halo_violations = 0
+        self.frames = 0
+        self.exchange_s = 0.0
+
+    # ---- particle creation: the host feeds spawned rows chunk by chunk (host.SPH.CreateParticles)
+    grid_first = True
+
+    def alloc_particles(self, n):
+        self.n_global = int(n)
+
+    def preview_grid(self, min_x, cell_size):
+        self._min_x, self._cell = np.float32(min_x), np.float32(cell_size)
+
+    def _planes(self, x):
+        rx = self.grid[0]
+        plane = np.floor(((np.asarray(x, dtype=np.float32) - self._min_x) / self._cell).astype(np.float32)).astype(np.int64)
+        return np.clip(plane, 0, rx - 1)
+
+    def box_may_matter(self, lo_x, hi_x):
+        lo, hi = self._planes([lo_x, hi_x])
+        return hi >= self.own[0] - 1 and lo <= self.own[1]
+
+    def add_rows(self, first_id, rows):
+        """rows: (k, 18) float32 AoS rows of global ids first_id .. first_id+k-1; only those in the
+        owned planes are kept (ghosts arrive with the first exchange)."""
+        plane = self._planes(rows[:, 0])
+        m = (plane >= self.own[0]) & (plane < self.own[1])
+        ids = (int(first_id) + np.flatnonzero(m)).astype(np.uint32)
+        self._rows.append(abi.records_from_aos(rows[m], ids))
+
+    def upload_particles(self, aos):
+        self.add_rows(0, np.asarray(aos, dtype=np.float32).reshape(-1, abi.PARTICLE_FLOATS))
+
+    def set_phase_table(self, phases):
+        pass            # slab records carry restDensity / viscosity / mass themselves
+
+    def set_phase_ids(self, ids):
+        pass
+
+    def apply_phase_table(self):
+        pass
+
+    # ---- grid: global resolution in, local slab out
+    def resize_grid(self, rx, ry, rz, cap):
+        if self.grid is not None:
+            if self.grid != (rx, ry, rz, cap):
+                raise NotImplementedError("slab mode needs a static grid (boundary cube must not move)")
+            return
+        self.grid = (rx, ry, rz, cap)
+        self.cells = rx * ry * rz
+        x0, x1 = slab_ranges(rx, self.world)[self.rank]
+        if x1 - x0 < 2 * self.ghost and self.world > 1:
+            raise ValueError(f"slab of {x1 - x0} planes is narrower than 2 x {self.ghost} ghost planes")
+        self.own = (x0, x1)
+        self.keep = (max(x0 - self.ghost, 0), min(x1 + self.ghost, rx))
+
+    def set_params(self, p):
+        self._params = p
+        if self._rows is not None:
+            self._distribute()
+        self.e.set_params(p)
+
+    def _distribute(self):
+        rx, ry, rz, cap = self.grid
+        x0, x1 = self.own
+        owned = np.concatenate(self._rows) if self._rows else np.zeros(0, dtype=abi.SLAB_RECORD_DTYPE)
+        self._rows = None
+        share = max(self.n_global // self.world, owned.shape[0], 1024)
+        capacity = int(share * self.capacity_factor) + 4096
+        self.port.configure(rx, self.keep[0], self.keep[1] - self.keep[0], ry, rz, cap, x0, x1, capacity)
+        self.port.upload_owned(owned)
+        self.n = owned.shape[0]
+
+    def set_delta_time(self, dt):
+        self.e.set_delta_time(dt)
+
+    # ---- the per-frame exchange
+    def exchange(self):
+        t0 = time.perf_counter()
+        x0, x1 = self.own
+        rx = self.grid[0]
+        left_below = x0 + self.ghost if self.rank > 0 else 0
+        right_from = x1 - self.ghost if self.rank < self.world - 1 else rx
+        if self.frames > 0:
+            shift = self.e.read_counter(abi.CTR_MAX_PLANE_SHIFT)
+            if 2 * (1 + shift) > self.ghost and self.world > 1:
+                self.halo_violations += 1
+        to_l, to_r = self.port.pack(left_below, right_from)
+        from_l, from_r = self.comm.exchange(to_l, to_r)
+        self.n = self.port.rebuild(self.keep[0], self.keep[1], from_l, from_r)
+        self.e.n = self.n
+        self.exchange_s += time.perf_counter() - t0
+
+    def step_frame(self, sub_steps, time_step):
+        if sub_steps != 1 and self.world > 1:
+            raise NotImplementedError("slab mode supports subSteps == 1 (no per-sub-step ghost refresh yet)")
+        self.exchange()
+        self.e.step_frame(sub_steps, time_step)
+        self.frames += 1
+
+    def dispatch(self, kernel_id, count):
+        if kernel_id == abi.K_CLEAR_GRID:
+            self.exchange()
+            self.e.dispatch(kernel_id, self.e.cells)
+        else:
+            self.e.dispatch(kernel_id, self.n)
+        if kernel_id == abi.K_VELOCITY_DAMPING:
+            self.frames += 1
+
+    def synchronize(self):
+        self.e.synchronize()
+
+    def reset_counter(self, which=abi.CTR_COLLISIONS):
+        self.e.reset_counter(which)
+
+    def read_counter(self, which=abi.CTR_COLLISIONS):
+        return self.e.read_counter(which)
+
+    def read_counter_global(self, which=abi.CTR_COLLISIONS):
+        return self.comm.allreduce_sum(self.e.read_counter(which))
+
+    def get_timings(self):
+        return self.e.get_timings()
+
+    def owned_records(self):
+        return self.port.download_owned()
+
+    def count_global(self):
+        return self.comm.allreduce_sum(int(self.owned_records().shape[0]))
+
+    def destroy(self):
+        self.e.destroy()
+
+
+# ------------------------------------------------------------------------------------------------
+# bench.py --gpus N (N > 1): BASELINE config 5, weak scaling, 8,388,608 particles per GPU
+# ------------------------------------------------------------------------------------------------
+def bench_main(args, rank, local_rank, world):
+    import json
+    import torch
+    import torch.distributed as dist
+    from . import scenes
+
+    # Rehearsal on a one-GPU box: SPH_BENCH_BACKEND=gloo SPH_BENCH_SHARE_GPU=1 runs all ranks on
+    # device 0 with host-staged messages.  The real run is one rank per GPU over RCCL.
+    backend = os.environ.get("SPH_BENCH_BACKEND", "nccl")
+    if os.environ.get("SPH_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    if not dist.is_initialized():
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    per_gpu = args.particles or 8388608
+    eng = abi.Engine(local_rank)
+    port = DevicePort(eng, local_rank, msg_capacity=max(per_gpu // 4, 65536))
+    comm = NeighbourComm(rank, world, torch.device("cuda", local_rank), backend=backend)
+    se = SlabEngine(port, comm, rank, world, ghost_planes=8)
+    sc = scenes.config5(se, gpus=world, per_gpu=per_gpu)
+    sc.sph.use_step_frame = True
+    sc.start()
+    for _ in range(args.warmup):
+        sc.frame()
+    eng.synchronize()
+    try:
+        eng.get_timings()
+    except abi.SphError:
+        pass
+    se.exchange_s = 0.0
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sc.frame()
+    eng.synchronize()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    tm = eng.get_timings()
+    n_total = comm.allreduce_sum(int(se.owned_records().shape[0]))
+    viol = comm.allreduce_sum(se.halo_violations)
+    overflow = comm.allreduce_sum(eng.read_counter(abi.CTR_BIN_OVERFLOW))
+    force_ms = comm.allreduce_max(tm["force_ms"])
+    if rank == 0:
+        sub = sc.sph.subSteps
+        n_local = se.n
+        achieved = 64.0 * n_local / (force_ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "particle-updates/sec", "value": n_total * sub * args.steps / dt, "unit": "particle-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"config5: {per_gpu} particles per GPU, {n_total} total, two-phase, x-slabs with "
+                                   f"8 ghost planes, one neighbour message per face per frame ({backend} send/recv)",
+                       "particles": n_total, "sub_steps": sub, "parallelism": f"slab{world}",
+                       "halo_violations": viol, "bin_overflow_cells": overflow,
+                       "exchange_ms_per_step_rank0": se.exchange_s / args.steps * 1e3},
+            "roofline": {"bound": "hbm", "kernel": "k_force_xsph_rows (CS_ForceXSPH), slowest rank", "achieved": achieved,
+                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "avg_launch_ms": force_ms},
+            "stage_ms_rank0": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
+        }))
+    eng.destroy()
+    dist.destroy_process_group()

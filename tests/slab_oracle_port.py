@@ -1,0 +1,119 @@
+"""CPU stand-in for sph_amd.slab.DevicePort, built on the oracle (TEST INFRASTRUCTURE).
+
+Lets the slab driver (partitioning, message classification, halo width, migration) run with
+world_size 2 on the gloo backend without a GPU.  The oracle keeps hashing on the GLOBAL grid, so
+the port only has to keep the local particle list: owned + ghosts, uploaded in ascending global
+id so that the oracle's bin order equals the engine's (cell, id) order."""
+import numpy as np
+import torch
+
+from sph_amd import abi
+
+REC = abi.SLAB_RECORD_BYTES
+
+
+class _Shim:
+    """The few Engine attributes SlabEngine touches directly."""
+
+    def __init__(self, port):
+        self._p = port
+        self.n = 0
+        self.cells = 0
+
+    def __getattr__(self, name):
+        return getattr(self._p.ora, name)
+
+    def step_frame(self, sub, ts):
+        self._p.ora.step_frame(sub, ts)
+        self._p.after_frame()
+
+    def dispatch(self, kernel, count):
+        self._p.ora.dispatch(kernel)
+        if kernel == abi.K_BUILD_GRID:
+            self._p.after_build()
+
+    def read_counter(self, which=0):
+        if which == abi.CTR_MAX_PLANE_SHIFT:
+            return self._p.max_shift
+        return self._p.ora.read_counter(which)
+
+
+class OraclePort:
+    def __init__(self, oracle):
+        self.ora = oracle
+        self.e = _Shim(self)
+        self.device = torch.device("cpu")
+        self.ids = np.zeros(0, np.uint32)          # global id of local particle k
+        self.owned_mask = None                     # owned at the last grid build (None = all)
+        self.max_shift = 0
+
+    def configure(self, rx_global, x_offset, rx_local, ry, rz, cap, own_lo, own_hi, capacity):
+        self.rx, self.own = rx_global, (own_lo, own_hi)
+        self.ora.resize_grid(rx_global, ry, rz, cap)
+        self.e.cells = rx_global * ry * rz
+
+    def _set_local(self, recs):
+        recs = recs[np.argsort(recs["id"], kind="stable")]
+        self.ids = recs["id"].copy()
+        n = recs.shape[0]
+        self.ora.alloc_particles(max(n, 1))
+        aos = abi.aos_from_records(recs) if n else np.zeros((1, 18), np.float32)
+        if n == 0:
+            aos[0, 0:3] = 1e9                      # a parked dummy; never owned
+            aos[0, 9] = aos[0, 11] = 1.0
+            self.ids = np.array([0xFFFFFFFF], np.uint32)
+        self.ora.upload_particles(aos)
+        self.ora._static_dirty = False
+        self.owned_mask = None
+        self.e.n = max(n, 1)
+        return n
+
+    def upload_owned(self, records):
+        self._set_local(np.array(records, copy=True))
+
+    def _planes(self, x, p):
+        c = np.floor(((x - np.float32(p.minBound[0])) / np.float32(p.cellSize)).astype(np.float32)).astype(np.int64)
+        return np.clip(c, 0, self.rx - 1)
+
+    def set_params_ref(self, p):
+        self.params = p
+
+    def _current(self):
+        aos = self.ora.download_particles()
+        recs = abi.records_from_aos(aos, self.ids)
+        valid = self.ids != 0xFFFFFFFF
+        owned = valid if self.owned_mask is None else (self.owned_mask & valid)
+        return recs, owned, self._planes(aos[:, 0], self.params)
+
+    def pack(self, left_below, right_from):
+        recs, owned, plane = self._current()
+        to_l = recs[owned & (plane < left_below)]
+        to_r = recs[owned & (plane >= right_from)]
+        return (torch.from_numpy(to_l.view(np.uint8).reshape(-1, REC).copy()),
+                torch.from_numpy(to_r.view(np.uint8).reshape(-1, REC).copy()))
+
+    def rebuild(self, keep_lo, keep_hi, from_left, from_right):
+        recs, owned, plane = self._current()
+        parts = [recs[owned & (plane >= keep_lo) & (plane < keep_hi)]]
+        for t in (from_left, from_right):
+            if t is not None and t.shape[0]:
+                r = np.frombuffer(t.contiguous().numpy().tobytes(), dtype=abi.SLAB_RECORD_DTYPE)
+                pl = self._planes(r["pos"][:, 0], self.params)
+                parts.append(r[(pl >= keep_lo) & (pl < keep_hi)])
+        return self._set_local(np.concatenate(parts))
+
+    def after_build(self):
+        aos = self.ora.download_particles()
+        self._bin_plane = self._planes(aos[:, 0], self.params)
+        self.owned_mask = (self._bin_plane >= self.own[0]) & (self._bin_plane < self.own[1])
+
+    def after_frame(self):
+        # the oracle ran the whole frame: ownership is by FRAME-START plane = the bins' plane
+        cop = self.ora.download_grid()[3].astype(np.int64)
+        self._bin_plane = cop % self.rx
+        self.owned_mask = (self._bin_plane >= self.own[0]) & (self._bin_plane < self.own[1])
+        self.max_shift = 0                          # not measured on this port
+
+    def download_owned(self):
+        recs, owned, _ = self._current()
+        return recs[owned]

@@ -11,6 +11,7 @@ from sph_amd.host import (SPH, CircularMotion, SpawnBox, SphereCollider, Time, T
 
 class RecordingEngine:
     """Stands in for ComputeShader/ComputeBuffer and records the call sequence."""
+    grid_first = False
 
     def __init__(self):
         self.calls = []
