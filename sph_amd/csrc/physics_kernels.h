@@ -202,20 +202,34 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
     const float4 p = posM[s];
     const int3 c = search_cell(P, p.x, p.y, p.z);
     float density = 0.0f;
-#pragma unroll 1
-    for (int dz = -1; dz <= 1; dz++) {
-#pragma unroll 1
-        for (int dy = -1; dy <= 1; dy++) {
-            const RowRange r = row_range(P, cellCum, c, dy, dz, true);
-            for (int j = r.a; j < r.e; j++) {
-                const float4 q = posM[j];
-                const float rSq = dist2_exact(p.x - q.x, p.y - q.y, p.z - q.z);
-                if (rSq < P.h2 && j != s) {
-                    const float diff = P.h2 - rSq;
-                    density += q.w * P.poly6 * diff * diff * diff;     // compute:180
-                }
-            }
+    auto visit = [&](const float4 q, int j) {
+        const float rSq = dist2_exact(p.x - q.x, p.y - q.y, p.z - q.z);
+        if (rSq < P.h2 && j != s) {
+            const float diff = P.h2 - rSq;
+            density += q.w * P.poly6 * diff * diff * diff;             // compute:180
         }
+    };
+    // The loop is latency-bound (one dependent gather per candidate), so keep loads in flight:
+    // the next row's range is fetched while this row is walked, and candidates are loaded four
+    // at a time (indices clamped to the row) before any of them is tested.  Order of the sum
+    // is unchanged.
+    RowRange r = row_range(P, cellCum, c, -1, -1, true);
+#pragma unroll 1
+    for (int t = 0; t < 9; t++) {
+        const int tn = t + 1;
+        const RowRange nxt = row_range(P, cellCum, c, tn % 3 - 1, tn / 3 - 1, tn < 9);
+        const int last = r.e - 1;
+        for (int j = r.a; j < r.e; j += 4) {
+            const float4 q0 = posM[j];
+            const float4 q1 = posM[min(j + 1, last)];
+            const float4 q2 = posM[min(j + 2, last)];
+            const float4 q3 = posM[min(j + 3, last)];
+            visit(q0, j);
+            if (j + 1 <= last) visit(q1, j + 1);
+            if (j + 2 <= last) visit(q2, j + 2);
+            if (j + 3 <= last) visit(q3, j + 3);
+        }
+        r = nxt;
     }
     const float r0 = rho0[s];
     density = fmaxf(density, r0);                                          // compute:186
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
     rhoP[s] = make_float2(density, pressure);
 }
 
-// One in-range pair of CS_ForceXSPH (compute:250-277) with FMA contraction and hardware
+// One in-range pair of CS_ForceXSPH (compute:250-277) with explicit FMAs and hardware
 // reciprocals / square root (1 ulp) instead of the 12 IEEE divides of the literal form; the
 // result is tolerance-checked against the oracle (1e-5 of field scale), not bit-compared.
 struct ForceAcc {
@@ -234,27 +248,35 @@ struct ForceAcc {
 __device__ __forceinline__ void force_pair(const DevParams& P, ForceAcc& A, const float4 p, const float4 v,
                                            float densitySelf, float selfTerm, const float4 q, const float4 u,
                                            const float2 o) {
-#pragma clang fp contract(fast)
+    // Every multiply-add is spelled out (fmaf) with contraction OFF, so that each inlined copy of
+    // this function is the same instruction sequence: a pair's contribution must not depend on
+    // where in a lane's FIFO it sits (slab runs are compared bit for bit with one-GPU runs).
+#pragma clang fp contract(off)
     const float rx = p.x - q.x, ry = p.y - q.y, rz = p.z - q.z;
     const float rSq = dist2_exact(rx, ry, rz);
     const float dist = __builtin_amdgcn_sqrtf(rSq) + 1e-6f;               // compute:250
     const float invd = __builtin_amdgcn_rcpf(dist);
     const float invRho = __builtin_amdgcn_rcpf(o.x);
     const float diff = P.h2 - rSq;
-    const float pressureTerm = selfTerm + o.y * invRho * invRho;          // compute:255-256
-    const float gs = P.spikyGradFactor * diff * diff * invd;              // gradW = gs * r  (compute:257)
+    const float pressureTerm = fmaf(o.y * invRho, invRho, selfTerm);      // compute:255-256
+    const float gs = (P.spikyGradFactor * diff) * (diff * invd);          // gradW = gs * r  (compute:257)
     const float gwx = gs * rx, gwy = gs * ry, gwz = gs * rz;
     const float pf = -q.w * pressureTerm;
     const float dvx = u.x - v.x, dvy = u.y - v.y, dvz = u.z - v.z;        // compute:261
     const float mor = q.w * invRho;                                       // m_j / rho_j
-    const float vm = 0.5f * (v.w + u.w) * mor * (P.viscLapFactor * (P.h - dist));   // compute:263-265
-    A.fx += pf * gwx + vm * dvx;                                          // compute:258, 265
-    A.fy += pf * gwy + vm * dvy;
-    A.fz += pf * gwz + vm * dvz;
-    A.cgx += mor * gwx; A.cgy += mor * gwy; A.cgz += mor * gwz;           // compute:268
-    A.cl += mor * (-P.lapColFactor * diff * (P.h2 - 5.0f * rSq));         // compute:269-270
-    const float wm = P.poly6 * diff * diff * diff * q.w * __builtin_amdgcn_rcpf(0.5f * (densitySelf + o.x));
-    A.vcx += dvx * wm; A.vcy += dvy * wm; A.vcz += dvz * wm;              // compute:276
+    const float vm = ((0.5f * (v.w + u.w)) * mor) * (P.viscLapFactor * (P.h - dist));   // compute:263-265
+    A.fx = fmaf(pf, gwx, fmaf(vm, dvx, A.fx));                            // compute:258, 265
+    A.fy = fmaf(pf, gwy, fmaf(vm, dvy, A.fy));
+    A.fz = fmaf(pf, gwz, fmaf(vm, dvz, A.fz));
+    A.cgx = fmaf(mor, gwx, A.cgx);                                        // compute:268
+    A.cgy = fmaf(mor, gwy, A.cgy);
+    A.cgz = fmaf(mor, gwz, A.cgz);
+    const float lapW = (-P.lapColFactor * diff) * fmaf(-5.0f, rSq, P.h2); // compute:269
+    A.cl = fmaf(mor, lapW, A.cl);                                         // compute:270
+    const float wm = ((P.poly6 * diff) * (diff * diff)) * (q.w * __builtin_amdgcn_rcpf(0.5f * (densitySelf + o.x)));
+    A.vcx = fmaf(dvx, wm, A.vcx);                                         // compute:276
+    A.vcy = fmaf(dvy, wm, A.vcy);
+    A.vcz = fmaf(dvz, wm, A.vcz);
     A.norm += wm;                                                         // compute:277
 }
 
@@ -265,7 +287,8 @@ __device__ __forceinline__ void force_pair(const DevParams& P, ForceAcc& A, cons
 //   drain: when any lane's FIFO is full (wave ballot), all lanes pop their hits in order and do
 //          the pair arithmetic.  FIFO order = visiting order, so each lane still sums its
 //          neighbours in the reference's order.
-constexpr int kHitQueue = 16;
+constexpr int kHitQueue = 20;   // FIFO depth per lane (20 KB of LDS per workgroup)
+constexpr int kScanUnroll = 4;  // candidates loaded per lane before any is tested
 
 __global__ __launch_bounds__(kBlock) void k_force_xsph_rows(DevParams P, const float4* __restrict__ posM,
                                                             const float4* __restrict__ velIn,
@@ -288,35 +311,50 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_rows(DevParams P, const f
     const int3 c = search_cell(P, p.x, p.y, p.z);
     int cnt = 0;
     auto drain = [&]() {
+        // two pairs per trip: six gathers in flight before the arithmetic starts
 #pragma unroll 1
-        for (int k = 0; k < kHitQueue; k++) {
+        for (int k = 0; k < kHitQueue; k += 2) {
             if (!__any(k < cnt)) break;
-            if (k < cnt) {
-                const int j = queue[k][threadIdx.x];
-                force_pair(P, A, p, v, densitySelf, selfTerm, posM[j], velIn[j], rhoP[j]);
-            }
+            const int j0 = (k < cnt) ? queue[k][threadIdx.x] : sl;
+            const int j1 = (k + 1 < cnt) ? queue[k + 1][threadIdx.x] : sl;
+            const float4 q0 = posM[j0], u0 = velIn[j0];
+            const float2 o0 = rhoP[j0];
+            const float4 q1 = posM[j1], u1 = velIn[j1];
+            const float2 o1 = rhoP[j1];
+            if (k < cnt) force_pair(P, A, p, v, densitySelf, selfTerm, q0, u0, o0);
+            if (k + 1 < cnt) force_pair(P, A, p, v, densitySelf, selfTerm, q1, u1, o1);
         }
         cnt = 0;
     };
-#pragma unroll 1
-    for (int dz = -1; dz <= 1; dz++) {
-#pragma unroll 1
-        for (int dy = -1; dy <= 1; dy++) {
-            const RowRange r = row_range(P, cellCum, c, dy, dz, live);
-            int j = r.a;
-            while (__any(j < r.e)) {
-                if (j < r.e) {
-                    const float4 q = posM[j];
-                    const float rSq = dist2_exact(p.x - q.x, p.y - q.y, p.z - q.z);
-                    if (rSq < P.h2 && j != s) {
-                        queue[cnt][threadIdx.x] = j;
-                        cnt++;
-                    }
-                }
-                j++;
-                if (__any(cnt == kHitQueue)) drain();
-            }
+    auto test = [&](const float4 q, int j) {
+        const float rSq = dist2_exact(p.x - q.x, p.y - q.y, p.z - q.z);
+        if (rSq < P.h2 && j != s) {
+            queue[cnt][threadIdx.x] = j;
+            cnt++;
         }
+    };
+    RowRange r = row_range(P, cellCum, c, -1, -1, live);
+#pragma unroll 1
+    for (int t = 0; t < 9; t++) {
+        const int tn = t + 1;
+        const RowRange nxt = row_range(P, cellCum, c, tn % 3 - 1, tn / 3 - 1, live && tn < 9);
+        const int last = r.e - 1;
+        int j = r.a;
+        while (__any(j < r.e)) {
+            if (j < r.e) {
+                const float4 q0 = posM[j];
+                const float4 q1 = posM[min(j + 1, last)];
+                const float4 q2 = posM[min(j + 2, last)];
+                const float4 q3 = posM[min(j + 3, last)];
+                test(q0, j);
+                if (j + 1 <= last) test(q1, j + 1);
+                if (j + 2 <= last) test(q2, j + 2);
+                if (j + 3 <= last) test(q3, j + 3);
+            }
+            j += kScanUnroll;
+            if (__any(cnt > kHitQueue - kScanUnroll)) drain();   // room for the next four
+        }
+        r = nxt;
     }
     drain();
     if (!valid) return;
