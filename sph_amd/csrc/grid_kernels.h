@@ -170,30 +170,30 @@ __global__ __launch_bounds__(kBlock) void k_sort_scatter(const uint32_t* __restr
     }
 }
 
-// ---- cell ranges: boundary detection on the sorted keys (previous key via wave shuffle) -------------
-__global__ __launch_bounds__(kBlock) void k_cell_ranges(const uint32_t* __restrict__ sortedKeys, int n,
-                                                        int* __restrict__ cellStart, int* __restrict__ cellEnd) {
+// ---- cumulative cell table ---------------------------------------------------------------------------
+// T[c] = number of particles whose cell index is <= c.  Built in two steps: (1) the last slot of every
+// run of equal keys marks T[key] = slot + 1 (everything else was zeroed), the neighbour keys coming
+// from wave shuffles; (2) the marks grow with the cell index, so an inclusive prefix MAX over cells
+// fills the empty cells.  Kernels index it through cellCum = T - 1 (cellCum[c] = #particles with key
+// < c): the bin of cell c is [cellCum[c], cellCum[c+1]) and any run of consecutive cells [c0, c1] is the
+// single slot range [cellCum[c0], cellCum[c1+1]) -- what the 3-cells-per-row neighbour search reads
+// with two loads; empty cells cost nothing.  T is 16-byte aligned so the scans move int4.
+__global__ __launch_bounds__(kBlock) void k_cell_marks(const uint32_t* __restrict__ sortedKeys, int n,
+                                                       int* __restrict__ T) {
     int k = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     uint32_t key = (k < n) ? sortedKeys[k] : 0xFFFFFFFFu;
-    uint32_t prev = __shfl_up(key, 1);
     uint32_t next = __shfl_down(key, 1);
     if (k < n) {
-        if (lane == 0) prev = (k > 0) ? sortedKeys[k - 1] : 0xFFFFFFFFu;
         if (lane == 63) next = (k + 1 < n) ? sortedKeys[k + 1] : 0xFFFFFFFFu;
         if (k + 1 >= n) next = 0xFFFFFFFFu;
-        if (prev != key) cellStart[key] = k;
-        if (next != key) cellEnd[key] = k + 1;
+        if (next != key) T[key] = k + 1;
     }
 }
 
-// ---- cumulative cell table: cellCum[c+1] = #particles whose cell index is <= c -----------------------
-// cellEnd[] holds (last slot + 1) for non-empty cells and 0 for empty ones, and those values grow
-// with the cell index, so an inclusive prefix MAX over cells is the running particle count.  With it
-// the bins of any run of consecutive cells [c0, c1] are one slot range [cellCum[c0], cellCum[c1+1]),
-// which is what the 3-cells-per-row neighbour search reads (2 loads per row, empties cost nothing).
-constexpr int kScanItems = 16;
-constexpr int kScanTile = kBlock * kScanItems;   // 4096 cells per block
+constexpr int kScanVec = 4;                              // int4 per thread per round
+constexpr int kScanRounds = 4;
+constexpr int kScanTile = kBlock * kScanVec * kScanRounds;   // 4096 cells per block
 
 __device__ __forceinline__ int wave_incl_max(int v, int lane) {
 #pragma unroll
@@ -204,19 +204,24 @@ __device__ __forceinline__ int wave_incl_max(int v, int lane) {
     return v;
 }
 
-__global__ __launch_bounds__(kBlock) void k_cum_block_max(const int* __restrict__ cellEnd, long long cells,
+// cells4 = number of int4 groups (the table is padded to a multiple of 4 cells with zeros)
+__global__ __launch_bounds__(kBlock) void k_cum_block_max(const int4* __restrict__ T4, long long cells4,
                                                           int* __restrict__ blockMax) {
     __shared__ int ws[4];
-    const long long base = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
+    const long long base = (long long)blockIdx.x * (kBlock * kScanRounds) + threadIdx.x;
     int m = 0;
 #pragma unroll
-    for (int i = 0; i < kScanItems; i++) {
-        long long c = base + i;
-        if (c < cells) m = max(m, cellEnd[c]);
+    for (int r = 0; r < kScanRounds; r++) {
+        const long long i = base + (long long)r * kBlock;
+        if (i < cells4) {
+            const int4 v = T4[i];
+            m = max(max(m, max(v.x, v.y)), max(v.z, v.w));
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    m = wave_incl_max(m, lane);
-    if (lane == 63) ws[wave] = m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+    if (lane == 0) ws[wave] = m;
     __syncthreads();
     if (threadIdx.x == 0) blockMax[blockIdx.x] = max(max(ws[0], ws[1]), max(ws[2], ws[3]));
 }
@@ -246,34 +251,29 @@ __global__ __launch_bounds__(kBlock) void k_cum_scan_blocks(int* __restrict__ bl
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_cum_write(const int* __restrict__ cellEnd, long long cells,
-                                                      const int* __restrict__ blockPrefix,
-                                                      int* __restrict__ cellCum) {
+// in-place inclusive prefix max of one 4096-cell tile, seeded with the tile's exclusive prefix
+__global__ __launch_bounds__(kBlock) void k_cum_write(int4* __restrict__ T4, long long cells4,
+                                                      const int* __restrict__ blockPrefix) {
     __shared__ int ws[4];
-    const long long base = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
-    int v[kScanItems];
-    int m = 0;
-#pragma unroll
-    for (int i = 0; i < kScanItems; i++) {
-        long long c = base + i;
-        v[i] = (c < cells) ? cellEnd[c] : 0;
-        m = max(m, v[i]);
-        v[i] = m;                       // thread-local inclusive max
-    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int incl = wave_incl_max(m, lane);
-    if (lane == 63) ws[wave] = incl;
-    __syncthreads();
-    int off = blockPrefix[blockIdx.x];
-    for (int w = 0; w < wave; w++) off = max(off, ws[w]);
-    int excl = __shfl_up(incl, 1);
-    if (lane == 0) excl = 0;
-    off = max(off, excl);
-    if (blockIdx.x == 0 && threadIdx.x == 0) cellCum[0] = 0;
-#pragma unroll
-    for (int i = 0; i < kScanItems; i++) {
-        long long c = base + i;
-        if (c < cells) cellCum[c + 1] = max(off, v[i]);
+    int carry = blockPrefix[blockIdx.x];
+    const long long base = (long long)blockIdx.x * (kBlock * kScanRounds) + threadIdx.x;
+#pragma unroll 1
+    for (int r = 0; r < kScanRounds; r++) {
+        const long long i = base + (long long)r * kBlock;
+        int4 v = (i < cells4) ? T4[i] : make_int4(0, 0, 0, 0);
+        v.y = max(v.y, v.x); v.z = max(v.z, v.y); v.w = max(v.w, v.z);      // thread-local
+        const int incl = wave_incl_max(v.w, lane);
+        __syncthreads();                                                    // ws free again
+        if (lane == 63) ws[wave] = incl;
+        __syncthreads();
+        int off = carry;
+        for (int w = 0; w < wave; w++) off = max(off, ws[w]);
+        int excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 0;
+        off = max(off, excl);
+        if (i < cells4) T4[i] = make_int4(max(v.x, off), max(v.y, off), max(v.z, off), max(v.w, off));
+        carry = max(carry, max(max(ws[0], ws[1]), max(ws[2], ws[3])));
     }
 }
 

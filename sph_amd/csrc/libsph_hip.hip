@@ -50,9 +50,9 @@ struct sph_ctx {
     int rx = 0, ry = 0, rz = 0, cap = 0;
     long long cells = 0;
     long long cellCapacity = 0;
-    int* cellStart = nullptr;
-    int* cellEnd = nullptr;
-    int* cellCum = nullptr;           // [cells + 1] running particle count by cell
+    int* cumBase = nullptr;           // allocation behind the cumulative cell table
+    int* cumT = nullptr;              // T[c] = #particles with cell <= c (16-byte aligned, T[-1] = 0)
+    int* cellCum = nullptr;           // = T - 1: cellCum[c] = #particles with cell < c; [cells + 1] entries
     int* cumBlocks = nullptr;         // per-4096-cell block maxima / prefixes
     uint32_t* keys[2] = {nullptr, nullptr};
     uint32_t* vals[2] = {nullptr, nullptr};
@@ -142,7 +142,8 @@ void freeParticles(sph_ctx* c) {
 }
 
 void freeGrid(sph_ctx* c) {
-    devFree(c->cellStart); devFree(c->cellEnd); devFree(c->cellCum); devFree(c->cumBlocks);
+    devFree(c->cumBase); devFree(c->cumBlocks);
+    c->cumT = c->cellCum = nullptr;
     c->cellCapacity = 0; c->cells = 0;
 }
 
@@ -251,8 +252,9 @@ StateSet curSet(sph_ctx* c) {
 
 // CS_ClearGrid (compute:104-111): a bin is a [start,end) range here, so clearing = zero ranges.
 int clearGrid(sph_ctx* c) {
-    HIP_TRY(c, hipMemsetAsync(c->cellStart, 0, sizeof(int) * (size_t)c->cells, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->cellEnd, 0, sizeof(int) * (size_t)c->cells, c->stream));
+    // T[-1 .. cells padded to int4): zero = "no particle in any cell"
+    const size_t padded = ((size_t)c->cells + 3) / 4 * 4;
+    HIP_TRY(c, hipMemsetAsync(c->cumBase, 0, sizeof(int) * (padded + 4), c->stream));
     c->gridValid = false;
     return SPH_OK;
 }
@@ -288,21 +290,21 @@ int buildGrid(sph_ctx* c) {
     }
     c->sortedKeys = c->keys[in];
     uint32_t* perm = c->vals[in];
-    hipLaunchKernelGGL(k_cell_ranges, dim3(nb), dim3(kBlock), 0, c->stream, c->sortedKeys, n, c->cellStart,
-                       c->cellEnd);
+    hipLaunchKernelGGL(k_cell_marks, dim3(nb), dim3(kBlock), 0, c->stream, c->sortedKeys, n, c->cumT);
     {   // cumulative cell table for the 3-cells-per-row search
+        const long long cells4 = (c->cells + 3) / 4;
         const int cb = (int)((c->cells + kScanTile - 1) / kScanTile);
-        hipLaunchKernelGGL(k_cum_block_max, dim3(cb), dim3(kBlock), 0, c->stream, c->cellEnd, c->cells, c->cumBlocks);
+        hipLaunchKernelGGL(k_cum_block_max, dim3(cb), dim3(kBlock), 0, c->stream, (const int4*)c->cumT, cells4,
+                           c->cumBlocks);
         hipLaunchKernelGGL(k_cum_scan_blocks, dim3(1), dim3(kBlock), 0, c->stream, c->cumBlocks, cb);
-        hipLaunchKernelGGL(k_cum_write, dim3(cb), dim3(kBlock), 0, c->stream, c->cellEnd, c->cells, c->cumBlocks,
-                           c->cellCum);
+        hipLaunchKernelGGL(k_cum_write, dim3(cb), dim3(kBlock), 0, c->stream, (int4*)c->cumT, cells4, c->cumBlocks);
     }
     hipLaunchKernelGGL(k_gather_ids, dim3(nb), dim3(kBlock), 0, c->stream, perm, src.origId, n, c->sid);
     StateSet dst = c->set[1 - c->cur];
     // velocities of the new order go to the set that does NOT hold the current ones
     dst.velV = c->set[1 - c->velCur].velV;
     hipLaunchKernelGGL(k_rank_in_cell, dim3(nb), dim3(kBlock), 0, c->stream, c->sortedKeys, perm, c->sid, n, c->cap,
-                       c->cellStart, c->cellEnd, c->perm2, dst.origId, c->counters);
+                       c->cellCum, c->cellCum + 1, c->perm2, dst.origId, c->counters);
     hipLaunchKernelGGL(k_permute_state, dim3(nb), dim3(kBlock), 0, c->stream, n, c->perm2, src, dst);
     CHECK_LAUNCH(c);
     c->cur = 1 - c->cur;
@@ -328,7 +330,7 @@ int dispatchKernel(sph_ctx* c, int id) {
             hipLaunchKernelGGL(k_density_pressure_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.rho0,
                                s.rhoP, c->cellCum, c->counters);
             hipLaunchKernelGGL(k_density_pressure, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.rho0, s.rhoP,
-                               c->cellStart, c->cellEnd, c->counters);
+                               c->cellCum, c->cellCum + 1, c->counters);
             if (c->slab)
                 hipLaunchKernelGGL(k_slab_plane_shift, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, c->sortedKeys,
                                    c->counters);
@@ -338,7 +340,7 @@ int dispatchKernel(sph_ctx* c, int id) {
             hipLaunchKernelGGL(k_force_xsph_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, s.rhoP,
                                s.acc, velOut, c->cellCum, c->counters);
             hipLaunchKernelGGL(k_force_xsph, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, s.rhoP, s.acc,
-                               velOut, c->cellStart, c->cellEnd, c->counters);
+                               velOut, c->cellCum, c->cellCum + 1, c->counters);
             c->velCur = 1 - c->velCur;
             break;
         }
@@ -509,9 +511,8 @@ int sph_resize_grid(sph_ctx* c, int rx, int ry, int rz, int max_per_cell) {
         freeGrid(c);
         long long want = cells + cells / 4;
         if (want > 0x7FFFFFFFll) want = 0x7FFFFFFFll;
-        int rc = devAlloc(c, &c->cellStart, (size_t)want);
-        if (!rc) rc = devAlloc(c, &c->cellEnd, (size_t)want);
-        if (!rc) rc = devAlloc(c, &c->cellCum, (size_t)want + 1);
+        int rc = devAlloc(c, &c->cumBase, (size_t)want + 16);
+        if (!rc) { c->cumT = c->cumBase + 4; c->cellCum = c->cumT - 1; }
         if (!rc) rc = devAlloc(c, &c->cumBlocks, (size_t)((want + kScanTile - 1) / kScanTile));
         if (rc) { freeGrid(c); return rc; }
         c->cellCapacity = want;
@@ -603,8 +604,8 @@ int sph_step_frame(sph_ctx* c, int sub_steps, float time_step) {
     if (c->slotPending[slot] && (rc = harvestSlot(c, slot))) return rc;
     hipEvent_t* ev = c->ev[slot];
     HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-    if ((rc = dispatchKernel(c, SPH_K_CLEAR_GRID))) return rc;               // SPH.cs:201
-    if ((rc = dispatchKernel(c, SPH_K_BUILD_GRID))) return rc;               // SPH.cs:204
+    // SPH.cs:201 + 204: CS_ClearGrid is the first step of the grid build here
+    if ((rc = dispatchKernel(c, SPH_K_BUILD_GRID))) return rc;
     HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     sph_set_delta_time(c, time_step / (float)sub_steps);                    // SPH.cs:207-208
     for (int s = 0; s < sub_steps; s++) {                                   // SPH.cs:210-219
@@ -659,8 +660,8 @@ int sph_download_grid(sph_ctx* c, int32_t* cell_start, int32_t* cell_end, int32_
     if (c->slab && cell_of_particle) return fail(c, SPH_E_STATE, "cell_of_particle is indexed by id: not available in slab mode");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t cb = sizeof(int) * (size_t)c->cells, nb = sizeof(int) * (size_t)c->n;
-    if (cell_start) HIP_TRY(c, hipMemcpyAsync(cell_start, c->cellStart, cb, hipMemcpyDeviceToHost, c->stream));
-    if (cell_end) HIP_TRY(c, hipMemcpyAsync(cell_end, c->cellEnd, cb, hipMemcpyDeviceToHost, c->stream));
+    if (cell_start) HIP_TRY(c, hipMemcpyAsync(cell_start, c->cellCum, cb, hipMemcpyDeviceToHost, c->stream));
+    if (cell_end) HIP_TRY(c, hipMemcpyAsync(cell_end, c->cellCum + 1, cb, hipMemcpyDeviceToHost, c->stream));
     if (sorted_ids)
         HIP_TRY(c, hipMemcpyAsync(sorted_ids, c->set[c->cur].origId, nb, hipMemcpyDeviceToHost, c->stream));
     if (cell_of_particle) {
@@ -690,7 +691,7 @@ int sph_download_neighbors(sph_ctx* c, int32_t* counts, int32_t* lists, int max_
     }
     StateSet s = curSet(c);
     hipLaunchKernelGGL(k_export_neighbors, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.origId,
-                       c->cellStart, c->cellEnd, c->cellCum, c->counters, dCounts, dLists, max_neighbors);
+                       c->cellCum, c->cellCum + 1, c->cellCum, c->counters, dCounts, dLists, max_neighbors);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(counts, dCounts, sizeof(int) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess && dLists) e = hipMemcpyAsync(lists, dLists, lb, hipMemcpyDeviceToHost, c->stream);

@@ -202,17 +202,17 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
     const float4 p = posM[s];
     const int3 c = search_cell(P, p.x, p.y, p.z);
     float density = 0.0f;
-    auto visit = [&](const float4 q, int j) {
+    // Branch-free body: a rejected candidate adds +0.0f, which leaves the running sum bit-identical
+    // (every term is >= 0), so no exec-mask juggling per candidate.
+    auto visit = [&](const float4 q, int j, bool inRow) {
         const float rSq = dist2_exact(p.x - q.x, p.y - q.y, p.z - q.z);
-        if (rSq < P.h2 && j != s) {
-            const float diff = P.h2 - rSq;
-            density += q.w * P.poly6 * diff * diff * diff;             // compute:180
-        }
+        const float diff = P.h2 - rSq;
+        const float term = q.w * P.poly6 * diff * diff * diff;        // compute:180
+        density += (inRow && rSq < P.h2 && j != s) ? term : 0.0f;
     };
-    // The loop is latency-bound (one dependent gather per candidate), so keep loads in flight:
-    // the next row's range is fetched while this row is walked, and candidates are loaded four
-    // at a time (indices clamped to the row) before any of them is tested.  Order of the sum
-    // is unchanged.
+    // Keep gathers in flight: the next row's range is fetched while this row is walked, and
+    // candidates are loaded four at a time (indices clamped to the row) before any is tested.
+    // Order of the sum is unchanged.
     RowRange r = row_range(P, cellCum, c, -1, -1, true);
 #pragma unroll 1
     for (int t = 0; t < 9; t++) {
@@ -224,10 +224,10 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
             const float4 q1 = posM[min(j + 1, last)];
             const float4 q2 = posM[min(j + 2, last)];
             const float4 q3 = posM[min(j + 3, last)];
-            visit(q0, j);
-            if (j + 1 <= last) visit(q1, j + 1);
-            if (j + 2 <= last) visit(q2, j + 2);
-            if (j + 3 <= last) visit(q3, j + 3);
+            visit(q0, j, true);
+            visit(q1, j + 1, j + 1 <= last);
+            visit(q2, j + 2, j + 2 <= last);
+            visit(q3, j + 3, j + 3 <= last);
         }
         r = nxt;
     }
