@@ -100,7 +100,10 @@ __global__ __launch_bounds__(kBlock) void k_sort_scatter(const uint32_t* __restr
                                                          uint32_t* __restrict__ vals_out, int n, int shift,
                                                          const uint32_t* __restrict__ blockHist, int numBlocks,
                                                          const uint32_t* __restrict__ digitTotal) {
-    __shared__ uint32_t waveCnt[4][kRadix];
+    // per-wave digit counters: only the owning wave touches its row, and a wave's LDS operations
+    // execute in issue order, so the ranking loop needs no workgroup barrier (volatile keeps the
+    // compiler from reordering the read-modify-write across iterations)
+    __shared__ volatile uint32_t waveCnt[4][kRadix];
     __shared__ uint32_t digitBase[kRadix];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int w = 0; w < 4; w++) waveCnt[w][threadIdx.x] = 0;
@@ -130,7 +133,11 @@ __global__ __launch_bounds__(kBlock) void k_sort_scatter(const uint32_t* __restr
         bool valid = i < n;
         key[it] = valid ? keys_in[i] : 0xFFFFFFFFu;
         val[it] = valid ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;
-        uint32_t d = (key[it] >> shift) & 255u;
+    }
+#pragma unroll
+    for (int it = 0; it < kSortItems; it++) {
+        const bool valid = base + it * kWave < n;
+        const uint32_t d = (key[it] >> shift) & 255u;
         // lanes holding the same digit (wave-wide match via 8 ballots)
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -144,10 +151,11 @@ __global__ __launch_bounds__(kBlock) void k_sort_scatter(const uint32_t* __restr
             before = waveCnt[wave][d];
             rank[it] = before + (uint32_t)__popcll(peers & ltMask);
         }
-        __syncthreads();   // everyone has read its counter before the leaders bump them
+        __builtin_amdgcn_wave_barrier();   // every lane has read its counter before the leaders bump them
         if (valid && (peers & ltMask) == 0ull) waveCnt[wave][d] = before + (uint32_t)__popcll(peers);
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
+    __syncthreads();
     {   // digit t: turn per-wave counts into global destinations
         const int d = threadIdx.x;
         uint32_t run = digitBase[d] + blockHist[(size_t)d * numBlocks + blockIdx.x];

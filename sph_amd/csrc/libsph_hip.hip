@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -86,6 +87,7 @@ struct sph_ctx {
     bool slotPending[kTimingRing] = {};
     int ringNext = 0;
     double stageSum[kNumEvents] = {};   // ms; [7] = whole frame
+    int timingLevel = 1;                // 0 none, 1 frame + density + force (default), 2 every stage
     int framesTimed = 0;
 };
 
@@ -219,14 +221,23 @@ int checkReady(sph_ctx* c, bool needGrid) {
 int harvestSlot(sph_ctx* c, int slot) {
     hipEvent_t* ev = c->ev[slot];
     HIP_TRY(c, hipEventSynchronize(ev[7]));
-    for (int k = 0; k < 7; k++) {
+    auto span = [&](int a, int b, int into) -> int {
         float t = 0;
-        HIP_TRY(c, hipEventElapsedTime(&t, ev[k], ev[k + 1]));
-        c->stageSum[k] += t;
+        HIP_TRY(c, hipEventElapsedTime(&t, ev[a], ev[b]));
+        c->stageSum[into] += t;
+        return SPH_OK;
+    };
+    int rc = SPH_OK;
+    if (c->timingLevel >= 2) {
+        for (int k = 0; k < 7 && !rc; k++) rc = span(k, k + 1, k);
+    } else {                       // level 1: grid build + half step share one span
+        rc = span(0, 2, 0);
+        if (!rc) rc = span(2, 3, 2);
+        if (!rc) rc = span(3, 4, 3);
+        if (!rc) rc = span(4, 7, 4);
     }
-    float t = 0;
-    HIP_TRY(c, hipEventElapsedTime(&t, ev[0], ev[7]));
-    c->stageSum[7] += t;
+    if (!rc) rc = span(0, 7, 7);
+    if (rc) return rc;
     c->framesTimed++;
     c->slotPending[slot] = false;
     return SPH_OK;
@@ -313,7 +324,7 @@ int buildGrid(sph_ctx* c) {
     return SPH_OK;
 }
 
-int dispatchKernel(sph_ctx* c, int id) {
+int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false) {
     const int n = c->n;
     c->dp.n = n;
     const int nb = blocksFor(n);
@@ -338,9 +349,9 @@ int dispatchKernel(sph_ctx* c, int id) {
         case SPH_K_FORCE_XSPH: {
             float4* velOut = c->set[1 - c->velCur].velV;
             hipLaunchKernelGGL(k_force_xsph_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, s.rhoP,
-                               s.acc, velOut, c->cellCum, c->counters);
+                               s.acc, velOut, c->cellCum, c->counters, fused ? 1 : 0);
             hipLaunchKernelGGL(k_force_xsph, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, s.rhoP, s.acc,
-                               velOut, c->cellCum, c->cellCum + 1, c->counters);
+                               velOut, c->cellCum, c->cellCum + 1, c->counters, fused ? 1 : 0);
             c->velCur = 1 - c->velCur;
             break;
         }
@@ -348,6 +359,12 @@ int dispatchKernel(sph_ctx* c, int id) {
             hipLaunchKernelGGL(k_half_step, dim3(nb), dim3(kBlock), 0, c->stream, n, c->dp.dt, s.posM, s.velV, s.acc);
             break;
         case SPH_K_VV_FULL_STEP:
+            if (fused) {   // + CS_BoundObs (+ CS_VelocityDamping after the last sub-step), one pass
+                hipLaunchKernelGGL(k_full_bound_damp, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, s.acc,
+                                   c->counters, c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr,
+                                   lastSub ? 1 : 0);
+                break;
+            }
             hipLaunchKernelGGL(k_full_step, dim3(nb), dim3(kBlock), 0, c->stream, n, c->dp.dt, s.velV, s.acc);
             break;
         case SPH_K_BOUND_OBS:
@@ -381,6 +398,7 @@ int sph_create(sph_ctx** out, int device_id) {
     sph_ctx* c = new (std::nothrow) sph_ctx();
     if (!c) return SPH_E_NOMEM;
     c->device = device_id;
+    if (const char* tl = getenv("SPH_HIP_TIMING")) c->timingLevel = atoi(tl);
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return SPH_E_HIP;
@@ -603,29 +621,35 @@ int sph_step_frame(sph_ctx* c, int sub_steps, float time_step) {
     const int slot = c->ringNext;
     if (c->slotPending[slot] && (rc = harvestSlot(c, slot))) return rc;
     hipEvent_t* ev = c->ev[slot];
-    HIP_TRY(c, hipEventRecord(ev[0], c->stream));
+    const int tl = c->timingLevel;
+    if (tl >= 1) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
     // SPH.cs:201 + 204: CS_ClearGrid is the first step of the grid build here
     if ((rc = dispatchKernel(c, SPH_K_BUILD_GRID))) return rc;
-    HIP_TRY(c, hipEventRecord(ev[1], c->stream));
+    if (tl >= 2) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     sph_set_delta_time(c, time_step / (float)sub_steps);                    // SPH.cs:207-208
+    // SPH.cs:210-222 with the dead and the purely streaming stages folded together (bit-identical
+    // results): CS_Clear is elided (density/pressure/acceleration are fully overwritten by the two
+    // neighbour kernels; the force kernel zeroes the acceleration of the particles it skips), and
+    // CS_VvFullStep + CS_BoundObs + (after the last sub-step) CS_VelocityDamping are one pass.
     for (int s = 0; s < sub_steps; s++) {                                   // SPH.cs:210-219
         const bool last = s == sub_steps - 1;
         if ((rc = dispatchKernel(c, SPH_K_VV_HALF_STEP))) return rc;
-        if (last) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
-        if ((rc = dispatchKernel(c, SPH_K_CLEAR))) return rc;
+        if (last && tl >= 1) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
         if ((rc = dispatchKernel(c, SPH_K_DENSITY_PRESSURE))) return rc;
-        if (last) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
-        if ((rc = dispatchKernel(c, SPH_K_FORCE_XSPH))) return rc;
-        if (last) HIP_TRY(c, hipEventRecord(ev[4], c->stream));
-        if ((rc = dispatchKernel(c, SPH_K_VV_FULL_STEP))) return rc;
-        if (last) HIP_TRY(c, hipEventRecord(ev[5], c->stream));
-        if ((rc = dispatchKernel(c, SPH_K_BOUND_OBS))) return rc;
-        if (last) HIP_TRY(c, hipEventRecord(ev[6], c->stream));
+        if (last && tl >= 1) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
+        if ((rc = dispatchKernel(c, SPH_K_FORCE_XSPH, true))) return rc;
+        if (last && tl >= 1) HIP_TRY(c, hipEventRecord(ev[4], c->stream));
+        if ((rc = dispatchKernel(c, SPH_K_VV_FULL_STEP, true, last))) return rc;
+        if (last && tl >= 2) {
+            HIP_TRY(c, hipEventRecord(ev[5], c->stream));
+            HIP_TRY(c, hipEventRecord(ev[6], c->stream));
+        }
     }
-    if ((rc = dispatchKernel(c, SPH_K_VELOCITY_DAMPING))) return rc;         // SPH.cs:222
-    HIP_TRY(c, hipEventRecord(ev[7], c->stream));
-    c->slotPending[slot] = true;
-    c->ringNext = (slot + 1) % kTimingRing;
+    if (tl >= 1) {
+        HIP_TRY(c, hipEventRecord(ev[7], c->stream));
+        c->slotPending[slot] = true;
+        c->ringNext = (slot + 1) % kTimingRing;
+    }
     return SPH_OK;
 }
 

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph(DevParams P, const float4
                                                        float4* __restrict__ velOut,
                                                        const int* __restrict__ cellStart,
                                                        const int* __restrict__ cellEnd,
-                                                       const int* __restrict__ counters) {
+                                                       const int* __restrict__ counters, int zeroDeadAcc) {
     if (counters[SPH_CTR_BIN_OVERFLOW] == 0) return;      // the fast path ran
     int s = blockIdx.x * kBlock + threadIdx.x;
     if (s >= P.n) return;
@@ -107,6 +107,7 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph(DevParams P, const float4
     const float densitySelf = dp.x;
     if (densitySelf < 1e-6f) {                                             // compute:207-211
         velOut[s] = v;
+        if (zeroDeadAcc) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
     float fx = 0.0f, fy = P.gravity * densitySelf, fz = 0.0f;              // compute:219
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_rows(DevParams P, const f
                                                             const float2* __restrict__ rhoP,
                                                             float4* __restrict__ acc, float4* __restrict__ velOut,
                                                             const int* __restrict__ cellCum,
-                                                            const int* __restrict__ counters) {
+                                                            const int* __restrict__ counters, int zeroDeadAcc) {
     __shared__ int queue[kHitQueue][kBlock];
     if (counters[SPH_CTR_BIN_OVERFLOW] != 0) return;      // the capped per-cell kernel runs instead
     const int s = blockIdx.x * kBlock + threadIdx.x;
@@ -360,6 +361,7 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_rows(DevParams P, const f
     if (!valid) return;
     if (!live) {
         velOut[s] = v;
+        if (zeroDeadAcc) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);   // what the elided CS_Clear would have left
         return;
     }
     {
@@ -411,8 +413,95 @@ __device__ __forceinline__ float dot3f(float ax, float ay, float az, float bx, f
     return (ax * bx + ay * by) + az * bz;
 }
 
-// CS_BoundObs (compute:340-486).  The per-collision InterlockedAdd (compute:418) becomes one
-// wave ballot + popcount and a single atomic per wave.
+// CS_BoundObs (compute:340-486) for one particle: OBB or AABB boundary, then the sphere obstacle.
+// Returns true when the OBB branch collided (what compute:418 counts).
+__device__ __forceinline__ bool bound_obs_body(const DevParams& P, float4& p, float4& v) {
+    bool collided = false;
+    if (P.obb) {
+        float lp[3], pen[3] = {0.f, 0.f, 0.f};
+        for (int r = 0; r < 3; r++)
+            lp[r] = ((P.Minv[r * 4 + 0] * p.x + P.Minv[r * 4 + 1] * p.y) + P.Minv[r * 4 + 2] * p.z) +
+                    P.Minv[r * 4 + 3] * 1.0f;                          // compute:351
+        const float E = 0.5f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {                                  // compute:357-392
+            if (lp[k] < -E) { pen[k] = -E - lp[k]; lp[k] = -E; collided = true; }
+            else if (lp[k] > E) { pen[k] = lp[k] - E; lp[k] = E; collided = true; }
+        }
+        if (collided) {
+            float wp[3];
+            for (int r = 0; r < 3; r++)
+                wp[r] = ((P.M[r * 4 + 0] * lp[0] + P.M[r * 4 + 1] * lp[1]) + P.M[r * 4 + 2] * lp[2]) +
+                        P.M[r * 4 + 3] * 1.0f;                         // compute:396
+            p.x = wp[0]; p.y = wp[1]; p.z = wp[2];
+            float ln[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                if (pen[k] > 0.0f) ln[k] = (lp[k] < 0.0f) ? -1.0f : 1.0f;          // compute:400-405
+            const float l = sqrtf(dot3f(ln[0], ln[1], ln[2], ln[0], ln[1], ln[2]));
+            ln[0] /= l; ln[1] /= l; ln[2] /= l;                        // compute:406
+            float wn[3];
+            for (int r = 0; r < 3; r++)
+                wn[r] = (P.M[r * 4 + 0] * ln[0] + P.M[r * 4 + 1] * ln[1]) + P.M[r * 4 + 2] * ln[2];  // 408
+            const float wl = sqrtf(dot3f(wn[0], wn[1], wn[2], wn[0], wn[1], wn[2]));
+            wn[0] /= wl; wn[1] /= wl; wn[2] /= wl;
+            const float d = dot3f(v.x, v.y, v.z, wn[0], wn[1], wn[2]);
+            float vv[3] = {v.x, v.y, v.z};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {                              // compute:411-415
+                float vN = d * wn[k];
+                float vT = vv[k] - vN;
+                vv[k] = (-vN) + vT;
+            }
+            v.x = vv[0]; v.y = vv[1]; v.z = vv[2];
+        }
+    } else {                                                           // compute:423-463
+        float pp[3] = {p.x, p.y, p.z}, vv[3] = {v.x, v.y, v.z};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float halfSize = P.boundsSize[k] * 0.5f;
+            const float mn = P.boundsCenter[k] - halfSize, mx = P.boundsCenter[k] + halfSize;
+            if (pp[k] < mn) {
+                pp[k] = mn;
+                if (vv[k] < 0) vv[k] = -vv[k] * 0.9f;
+            } else if (pp[k] > mx) {
+                pp[k] = mx;
+                if (vv[k] > 0) vv[k] = -vv[k] * 0.9f;
+            }
+        }
+        p.x = pp[0]; p.y = pp[1]; p.z = pp[2];
+        v.x = vv[0]; v.y = vv[1]; v.z = vv[2];
+    }
+    if (P.obstacleRadius > 0.0f) {                                     // compute:467-483
+        const float tx = p.x - P.obstaclePos[0], ty = p.y - P.obstaclePos[1], tz = p.z - P.obstaclePos[2];
+        const float dist = sqrtf(dot3f(tx, ty, tz, tx, ty, tz));
+        if (dist < P.obstacleRadius && dist > 1e-6f) {
+            const float penetration = P.obstacleRadius - dist;
+            const float nx = tx / dist, ny = ty / dist, nz = tz / dist;
+            p.x += nx * penetration; p.y += ny * penetration; p.z += nz * penetration;
+            const float d = dot3f(v.x, v.y, v.z, nx, ny, nz);
+            v.x = (v.x - 2.0f * nx * d) * P.collisionDamping;          // reflect(v, n) * damping
+            v.y = (v.y - 2.0f * ny * d) * P.collisionDamping;
+            v.z = (v.z - 2.0f * nz * d) * P.collisionDamping;
+        } else if (dist <= 1e-6f) {
+            p.y += P.obstacleRadius + 0.01f;
+            const float d = v.y;                                       // dot(v, (0,1,0))
+            v.x = (v.x - 2.0f * 0.0f * d) * P.collisionDamping;
+            v.y = (v.y - 2.0f * 1.0f * d) * P.collisionDamping;
+            v.z = (v.z - 2.0f * 0.0f * d) * P.collisionDamping;
+        }
+    }
+    return collided;
+}
+
+__device__ __forceinline__ bool slot_is_owned(const DevParams& P, const uint32_t* __restrict__ sortedKeys, int s) {
+    if (!sortedKeys) return true;
+    const int plane = (int)(sortedKeys[s] % (uint32_t)P.rx);
+    return plane >= P.ownLo && plane < P.ownHi;
+}
+
+// CS_BoundObs kernel.  The per-collision InterlockedAdd (compute:418) becomes one wave ballot +
+// popcount and a single atomic per wave; in slab mode ghost copies are counted by their owner.
 __global__ __launch_bounds__(kBlock) void k_bound_obs(DevParams P, float4* __restrict__ posM,
                                                       float4* __restrict__ velV, int* __restrict__ counters,
                                                       const uint32_t* __restrict__ sortedKeys) {
@@ -420,86 +509,39 @@ __global__ __launch_bounds__(kBlock) void k_bound_obs(DevParams P, float4* __res
     bool collided = false;
     if (s < P.n) {
         float4 p = posM[s], v = velV[s];
-        if (P.obb) {
-            float lp[3], pen[3] = {0.f, 0.f, 0.f};
-            for (int r = 0; r < 3; r++)
-                lp[r] = ((P.Minv[r * 4 + 0] * p.x + P.Minv[r * 4 + 1] * p.y) + P.Minv[r * 4 + 2] * p.z) +
-                        P.Minv[r * 4 + 3] * 1.0f;                          // compute:351
-            const float E = 0.5f;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {                                  // compute:357-392
-                if (lp[k] < -E) { pen[k] = -E - lp[k]; lp[k] = -E; collided = true; }
-                else if (lp[k] > E) { pen[k] = lp[k] - E; lp[k] = E; collided = true; }
-            }
-            if (collided) {
-                float wp[3];
-                for (int r = 0; r < 3; r++)
-                    wp[r] = ((P.M[r * 4 + 0] * lp[0] + P.M[r * 4 + 1] * lp[1]) + P.M[r * 4 + 2] * lp[2]) +
-                            P.M[r * 4 + 3] * 1.0f;                         // compute:396
-                p.x = wp[0]; p.y = wp[1]; p.z = wp[2];
-                float ln[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-                    if (pen[k] > 0.0f) ln[k] = (lp[k] < 0.0f) ? -1.0f : 1.0f;          // compute:400-405
-                const float l = sqrtf(dot3f(ln[0], ln[1], ln[2], ln[0], ln[1], ln[2]));
-                ln[0] /= l; ln[1] /= l; ln[2] /= l;                        // compute:406
-                float wn[3];
-                for (int r = 0; r < 3; r++)
-                    wn[r] = (P.M[r * 4 + 0] * ln[0] + P.M[r * 4 + 1] * ln[1]) + P.M[r * 4 + 2] * ln[2];  // 408
-                const float wl = sqrtf(dot3f(wn[0], wn[1], wn[2], wn[0], wn[1], wn[2]));
-                wn[0] /= wl; wn[1] /= wl; wn[2] /= wl;
-                const float d = dot3f(v.x, v.y, v.z, wn[0], wn[1], wn[2]);
-                float vv[3] = {v.x, v.y, v.z};
-#pragma unroll
-                for (int k = 0; k < 3; k++) {                              // compute:411-415
-                    float vN = d * wn[k];
-                    float vT = vv[k] - vN;
-                    vv[k] = (-vN) + vT;
-                }
-                v.x = vv[0]; v.y = vv[1]; v.z = vv[2];
-            }
-        } else {                                                           // compute:423-463
-            float pp[3] = {p.x, p.y, p.z}, vv[3] = {v.x, v.y, v.z};
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const float halfSize = P.boundsSize[k] * 0.5f;
-                const float mn = P.boundsCenter[k] - halfSize, mx = P.boundsCenter[k] + halfSize;
-                if (pp[k] < mn) {
-                    pp[k] = mn;
-                    if (vv[k] < 0) vv[k] = -vv[k] * 0.9f;
-                } else if (pp[k] > mx) {
-                    pp[k] = mx;
-                    if (vv[k] > 0) vv[k] = -vv[k] * 0.9f;
-                }
-            }
-            p.x = pp[0]; p.y = pp[1]; p.z = pp[2];
-            v.x = vv[0]; v.y = vv[1]; v.z = vv[2];
-        }
-        if (P.obstacleRadius > 0.0f) {                                     // compute:467-483
-            const float tx = p.x - P.obstaclePos[0], ty = p.y - P.obstaclePos[1], tz = p.z - P.obstaclePos[2];
-            const float dist = sqrtf(dot3f(tx, ty, tz, tx, ty, tz));
-            if (dist < P.obstacleRadius && dist > 1e-6f) {
-                const float penetration = P.obstacleRadius - dist;
-                const float nx = tx / dist, ny = ty / dist, nz = tz / dist;
-                p.x += nx * penetration; p.y += ny * penetration; p.z += nz * penetration;
-                const float d = dot3f(v.x, v.y, v.z, nx, ny, nz);
-                v.x = (v.x - 2.0f * nx * d) * P.collisionDamping;          // reflect(v, n) * damping
-                v.y = (v.y - 2.0f * ny * d) * P.collisionDamping;
-                v.z = (v.z - 2.0f * nz * d) * P.collisionDamping;
-            } else if (dist <= 1e-6f) {
-                p.y += P.obstacleRadius + 0.01f;
-                const float d = v.y;                                       // dot(v, (0,1,0))
-                v.x = (v.x - 2.0f * 0.0f * d) * P.collisionDamping;
-                v.y = (v.y - 2.0f * 1.0f * d) * P.collisionDamping;
-                v.z = (v.z - 2.0f * 0.0f * d) * P.collisionDamping;
-            }
-        }
+        collided = bound_obs_body(P, p, v) && slot_is_owned(P, sortedKeys, s);
         posM[s] = p;
         velV[s] = v;
-        if (sortedKeys) {   // slab mode: ghost copies are counted by their owner
-            const int plane = (int)(sortedKeys[s] % (uint32_t)P.rx);
-            collided = collided && plane >= P.ownLo && plane < P.ownHi;
-        }
+    }
+    const unsigned long long m = __ballot(collided);
+    if (m && (threadIdx.x & 63) == 0) atomicAdd(&counters[SPH_CTR_COLLISIONS], __popcll(m));
+}
+
+__device__ __forceinline__ void damp_velocity(float4& v) {                 // compute:499-507
+    const float speed = sqrtf((v.x * v.x + v.y * v.y) + v.z * v.z);
+    const float k = (speed < 0.2f) ? 0.98f : 0.999f;
+    v.x *= k; v.y *= k; v.z *= k;
+}
+
+// sph_step_frame's tail: CS_VvFullStep + CS_BoundObs (+ CS_VelocityDamping after the last sub-step)
+// in one pass over the particles -- the same operations in the same order per particle, so the
+// result is bit-identical to the three separate dispatches; 1 read + 1 write instead of 3 + 3.
+__global__ __launch_bounds__(kBlock) void k_full_bound_damp(DevParams P, float4* __restrict__ posM,
+                                                            float4* __restrict__ velV,
+                                                            const float4* __restrict__ acc,
+                                                            int* __restrict__ counters,
+                                                            const uint32_t* __restrict__ sortedKeys, int damp) {
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    bool collided = false;
+    if (s < P.n) {
+        float4 p = posM[s], v = velV[s];
+        const float4 a = acc[s];
+        const float hdt = 0.5f * P.dt;
+        v.x += hdt * a.x; v.y += hdt * a.y; v.z += hdt * a.z;              // compute:332
+        collided = bound_obs_body(P, p, v) && slot_is_owned(P, sortedKeys, s);
+        if (damp) damp_velocity(v);
+        posM[s] = p;
+        velV[s] = v;
     }
     const unsigned long long m = __ballot(collided);
     if (m && (threadIdx.x & 63) == 0) atomicAdd(&counters[SPH_CTR_COLLISIONS], __popcll(m));
