@@ -168,6 +168,24 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph(DevParams P, const float4
 // cumulative table with two loads.  Visiting order is unchanged: z, y, then x-1, x, x+1, then id.
 struct RowRange { int a, e; };
 
+#ifndef SPH_XCD_RUN
+#define SPH_XCD_RUN 16
+#endif
+// XCD-aware workgroup -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs, each with
+// its own 4 MiB L2; consecutive tiles of the (cell, id) order share most of their neighbour rows, so
+// give every XCD one CONTIGUOUS eighth of the tiles instead of every eighth tile: its L2 then holds
+// an eighth of the particle arrays (plus a halo) instead of seeing all of them.  Bijective for any
+// grid size (MI355X guide, T1); affects speed only, never results.
+__device__ __forceinline__ int xcd_tile(int bid, int nwg) {
+    // groups of kXcdRun consecutive tiles stay on one XCD; groups are dealt round-robin so that
+    // regions of different cost per particle (dense / sparse, phase A / phase B) spread evenly
+    constexpr int kXcdRun = SPH_XCD_RUN;
+    const int full = nwg / (8 * kXcdRun) * (8 * kXcdRun);
+    if (bid >= full) return bid;                     // ragged tail: identity
+    const int g = bid / (8 * kXcdRun), w = bid % (8 * kXcdRun);
+    return g * (8 * kXcdRun) + (w & 7) * kXcdRun + (w >> 3);
+}
+
 __device__ __forceinline__ int3 search_cell(const DevParams& P, float px, float py, float pz) {
     int3 c = cell_unclamped(P, px, py, pz);
     c.x = min(max(c.x, -2), P.rxg + 1);
@@ -198,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
                                                                   const int* __restrict__ cellCum,
                                                                   const int* __restrict__ counters) {
     if (counters[SPH_CTR_BIN_OVERFLOW] != 0) return;      // the capped per-cell kernel runs instead
-    const int s = blockIdx.x * kBlock + threadIdx.x;
+    const int s = xcd_tile(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
     if (s >= P.n) return;
     const float4 p = posM[s];
     const int3 c = search_cell(P, p.x, p.y, p.z);
@@ -299,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_rows(DevParams P, const f
                                                             const int* __restrict__ counters, int zeroDeadAcc) {
     __shared__ int queue[kHitQueue][kBlock];
     if (counters[SPH_CTR_BIN_OVERFLOW] != 0) return;      // the capped per-cell kernel runs instead
-    const int s = blockIdx.x * kBlock + threadIdx.x;
+    const int s = xcd_tile(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
     const bool valid = s < P.n;
     const int sl = valid ? s : 0;
     const float4 p = posM[sl];
