@@ -26,6 +26,19 @@ FORCE_BYTES_PER_PARTICLE = 64   # R pos12 vel12 rho4 p4 visc4 mass4
 DENSITY_BYTES_PER_PARTICLE = 28
 
 
+def measured_traffic(kernel, workload, n):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r1_traffic.json,
+    collected with scripts/gpu_pmc.sh in separate --pmc runs); None if not measured for this workload."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+        if t["workload"] != workload or t["particles"] != n:
+            return None
+        k = t["kernels"][kernel]
+        return (2.0 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024.0
+    except Exception:
+        return None
+
+
 def cpu_baseline(scene_builder, start_state, frames_done, budget_s=15.0):
     """Times the OpenMP oracle (kind "port") on the same workload, continuing from the state the
     GPU reached after warm-up, for a bounded number of frames."""
@@ -130,8 +143,9 @@ def main():
                                f"grid {sc.sph.gridResolutionX}x{sc.sph.gridResolutionY}x{sc.sph.gridResolutionZ}",
                    "particles": n, "sub_steps": sub, "parallelism": "1 GPU",
                    "bin_overflow_cells": overflow},
-        "roofline": {"bound": "hbm", "kernel": "k_force_xsph (CS_ForceXSPH)", "achieved": achieved,
-                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+        "roofline": {"bound": "hbm", "kernel": "k_force_xsph_rows (CS_ForceXSPH)", "achieved": achieved,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": measured_traffic("k_force_xsph_rows", wl, n),
                      "alg_bytes_per_particle": FORCE_BYTES_PER_PARTICLE, "avg_launch_ms": tm["force_ms"],
                      "density_kernel": {"achieved": dens_gbps, "frac": dens_gbps / HBM_PEAK_GBPS,
                                         "alg_bytes_per_particle": DENSITY_BYTES_PER_PARTICLE,
