@@ -340,8 +340,6 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false)
         case SPH_K_DENSITY_PRESSURE:
             hipLaunchKernelGGL(k_density_pressure_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.rho0,
                                s.rhoP, c->cellCum, c->counters);
-            hipLaunchKernelGGL(k_density_pressure, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.rho0, s.rhoP,
-                               c->cellCum, c->cellCum + 1, c->counters);
             if (c->slab)
                 hipLaunchKernelGGL(k_slab_plane_shift, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, c->sortedKeys,
                                    c->counters);
@@ -350,8 +348,6 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false)
             float4* velOut = c->set[1 - c->velCur].velV;
             hipLaunchKernelGGL(k_force_xsph_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, s.rhoP,
                                s.acc, velOut, c->cellCum, c->counters, fused ? 1 : 0);
-            hipLaunchKernelGGL(k_force_xsph, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, s.rhoP, s.acc,
-                               velOut, c->cellCum, c->cellCum + 1, c->counters, fused ? 1 : 0);
             c->velCur = 1 - c->velCur;
             break;
         }

@@ -59,110 +59,7 @@ __global__ __launch_bounds__(kBlock) void k_clear(int n, float4* __restrict__ ac
     rhoP[s] = make_float2(rho0[s], 0.f);
 }
 
-// CS_DensityPressure (compute:142-193), per-cell path with the bin cap (rule O2): runs only when
-// some bin overflowed at the last grid build.
-__global__ __launch_bounds__(kBlock) void k_density_pressure(DevParams P, const float4* __restrict__ posM,
-                                                             const float* __restrict__ rho0,
-                                                             float2* __restrict__ rhoP,
-                                                             const int* __restrict__ cellStart,
-                                                             const int* __restrict__ cellEnd,
-                                                             const int* __restrict__ counters) {
-    if (counters[SPH_CTR_BIN_OVERFLOW] == 0) return;      // the fast path ran
-    int s = blockIdx.x * kBlock + threadIdx.x;
-    if (s >= P.n) return;
-    const float4 p = posM[s];
-    float density = 0.0f;
-    for_each_candidate(P, cellStart, cellEnd, s, p.x, p.y, p.z, [&](int j) {
-        const float4 q = posM[j];
-        const float rx = p.x - q.x, ry = p.y - q.y, rz = p.z - q.z;
-        const float rSq = dist2_exact(rx, ry, rz);
-        if (rSq < P.h2) {
-            const float diff = P.h2 - rSq;
-            density += q.w * P.poly6 * diff * diff * diff;                 // compute:180
-        }
-    });
-    const float r0 = rho0[s];
-    density = fmaxf(density, r0);                                          // compute:186
-    const float localB = r0 * (P.soundSpeed * P.soundSpeed) / P.gamma;     // compute:189
-    const float pressure = localB * (powf(density / r0, P.gamma) - 1.0f);  // compute:190
-    rhoP[s] = make_float2(density, pressure);
-}
-
-// CS_ForceXSPH (compute:199-303).  Neighbour velocities come from velIn, the own corrected
-// velocity goes to velOut (a different buffer): the Jacobi reading of the reference's in-place
-// update (ORACLE rule O3).
-__global__ __launch_bounds__(kBlock) void k_force_xsph(DevParams P, const float4* __restrict__ posM,
-                                                       const float4* __restrict__ velIn,
-                                                       const float2* __restrict__ rhoP, float4* __restrict__ acc,
-                                                       float4* __restrict__ velOut,
-                                                       const int* __restrict__ cellStart,
-                                                       const int* __restrict__ cellEnd,
-                                                       const int* __restrict__ counters, int zeroDeadAcc) {
-    if (counters[SPH_CTR_BIN_OVERFLOW] == 0) return;      // the fast path ran
-    int s = blockIdx.x * kBlock + threadIdx.x;
-    if (s >= P.n) return;
-    const float4 p = posM[s];
-    const float4 v = velIn[s];
-    const float2 dp = rhoP[s];
-    const float densitySelf = dp.x;
-    if (densitySelf < 1e-6f) {                                             // compute:207-211
-        velOut[s] = v;
-        if (zeroDeadAcc) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
-    float fx = 0.0f, fy = P.gravity * densitySelf, fz = 0.0f;              // compute:219
-    float cgx = 0.f, cgy = 0.f, cgz = 0.f, colorLaplacian = 0.f;
-    float vcx = 0.f, vcy = 0.f, vcz = 0.f, normFactor = 0.f;
-    const float selfTerm = dp.y / (densitySelf * densitySelf);
-    for_each_candidate(P, cellStart, cellEnd, s, p.x, p.y, p.z, [&](int j) {
-        const float4 q = posM[j];
-        const float rx = p.x - q.x, ry = p.y - q.y, rz = p.z - q.z;
-        const float rSq = dist2_exact(rx, ry, rz);
-        if (rSq < P.h2) {
-            const float4 u = velIn[j];
-            const float2 o = rhoP[j];
-            const float dist = sqrtf(rSq) + 1e-6f;                         // compute:250
-            const float dirx = rx / dist, diry = ry / dist, dirz = rz / dist;
-            const float diff = P.h2 - rSq;
-            const float pressureTerm = selfTerm + (o.y / (o.x * o.x));     // compute:255-256
-            const float gs = P.spikyGradFactor * diff * diff;
-            const float gwx = gs * dirx, gwy = gs * diry, gwz = gs * dirz; // compute:257
-            const float pf = -q.w * pressureTerm;
-            fx += pf * gwx; fy += pf * gwy; fz += pf * gwz;                // compute:258
-            const float dvx = u.x - v.x, dvy = u.y - v.y, dvz = u.z - v.z; // compute:261
-            const float lapWv = P.viscLapFactor * (P.h - dist);            // compute:263
-            const float vm = (0.5f * (v.w + u.w)) * q.w;                   // compute:264-265
-            fx += vm * dvx / o.x * lapWv;
-            fy += vm * dvy / o.x * lapWv;
-            fz += vm * dvz / o.x * lapWv;
-            cgx += q.w * gwx / o.x;                                        // compute:268
-            cgy += q.w * gwy / o.x;
-            cgz += q.w * gwz / o.x;
-            const float lapW = -P.lapColFactor * (P.h2 - rSq) * (P.h2 - 5.0f * rSq);  // compute:269
-            colorLaplacian += q.w * lapW / o.x;                            // compute:270
-            const float W = P.poly6 * diff * diff * diff;                  // compute:274
-            const float mr = q.w / (0.5f * (densitySelf + o.x));           // compute:275
-            vcx += dvx * W * mr; vcy += dvy * W * mr; vcz += dvz * W * mr; // compute:276
-            normFactor += W * mr;                                          // compute:277
-        }
-    });
-    const float gradMag = sqrtf((cgx * cgx + cgy * cgy) + cgz * cgz);      // compute:285
-    if (gradMag > P.stThreshold) {
-        const float curvature = colorLaplacian / (gradMag + 1e-6f);
-        const float st = -P.sigma * curvature;
-        fx += st * (cgx / gradMag); fy += st * (cgy / gradMag); fz += st * (cgz / gradMag);
-    }
-    acc[s] = make_float4(fx / densitySelf, fy / densitySelf, fz / densitySelf, 0.f);   // compute:293
-    float4 vo = v;
-    if (normFactor > 1e-6f) {                                              // compute:296-300
-        const float sc = P.xsphEps / normFactor;
-        vo.x += vcx * sc; vo.y += vcy * sc; vo.z += vcz * sc;
-    }
-    velOut[s] = vo;
-}
-
-
-// ---- fast path: no bin overflowed (counters[SPH_CTR_BIN_OVERFLOW] == 0) ---------------------------------
+// ---- the neighbour kernels -----------------------------------------------------------------------------
 // The three x-neighbour cells of one (y, z) row are adjacent in the linear cell index
 // (compute:127), hence adjacent in the sorted order: their bins are ONE slot range, read from the
 // cumulative table with two loads.  Visiting order is unchanged: z, y, then x-1, x, x+1, then id.
@@ -208,6 +105,24 @@ __device__ __forceinline__ RowRange row_range(const DevParams& P, const int* __r
     return r;
 }
 
+// The t-th candidate range of a particle, in visiting order.  Normal case (no bin overflowed):
+// 9 ranges, one per (dy, dz) row, each covering the three x-neighbour cells.  If some bin
+// overflowed at the last grid build (capped != 0): 27 ranges, one per cell, each cut to the
+// reference's bin capacity (rule O2: the first `cap` ids of a bin are visible).
+__device__ __forceinline__ RowRange range_at(const DevParams& P, const int* __restrict__ cellCum, int3 c, int t,
+                                             bool capped, bool live) {
+    if (!capped) return row_range(P, cellCum, c, t % 3 - 1, t / 3 - 1, live && t < 9);
+    RowRange r{0, 0};
+    const int xg = c.x + (t % 3 - 1), y = c.y + ((t / 3) % 3 - 1), z = c.z + (t / 9 - 1);
+    const int x = xg - P.xoff;
+    if (live && t < 27 && xg >= 0 && xg < P.rxg && x >= 0 && x < P.rx && y >= 0 && y < P.ry && z >= 0 && z < P.rz) {
+        const int ci = x + y * P.rx + z * P.rx * P.ry;
+        r.a = cellCum[ci];
+        r.e = min(cellCum[ci + 1], r.a + P.cap);
+    }
+    return r;
+}
+
 // CS_DensityPressure (compute:142-193), fast path.  Same operations in the same order as the
 // per-cell kernel below, so the density is bit-identical to the oracle's.
 __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, const float4* __restrict__ posM,
@@ -215,7 +130,8 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
                                                                   float2* __restrict__ rhoP,
                                                                   const int* __restrict__ cellCum,
                                                                   const int* __restrict__ counters) {
-    if (counters[SPH_CTR_BIN_OVERFLOW] != 0) return;      // the capped per-cell kernel runs instead
+    const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
+    const int nRanges = capped ? 27 : 9;
     const int s = xcd_tile(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
     if (s >= P.n) return;
     const float4 p = posM[s];
@@ -232,11 +148,10 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
     // Keep gathers in flight: the next row's range is fetched while this row is walked, and
     // candidates are loaded four at a time (indices clamped to the row) before any is tested.
     // Order of the sum is unchanged.
-    RowRange r = row_range(P, cellCum, c, -1, -1, true);
+    RowRange r = range_at(P, cellCum, c, 0, capped, true);
 #pragma unroll 1
-    for (int t = 0; t < 9; t++) {
-        const int tn = t + 1;
-        const RowRange nxt = row_range(P, cellCum, c, tn % 3 - 1, tn / 3 - 1, tn < 9);
+    for (int t = 0; t < nRanges; t++) {
+        const RowRange nxt = range_at(P, cellCum, c, t + 1, capped, t + 1 < nRanges);
         const int last = r.e - 1;
         for (int j = r.a; j < r.e; j += 4) {
             const float4 q0 = posM[j];
@@ -316,7 +231,8 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_rows(DevParams P, const f
                                                             const int* __restrict__ cellCum,
                                                             const int* __restrict__ counters, int zeroDeadAcc) {
     __shared__ int queue[kHitQueue][kBlock];
-    if (counters[SPH_CTR_BIN_OVERFLOW] != 0) return;      // the capped per-cell kernel runs instead
+    const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
+    const int nRanges = capped ? 27 : 9;
     const int s = xcd_tile(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
     const bool valid = s < P.n;
     const int sl = valid ? s : 0;
@@ -352,11 +268,10 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_rows(DevParams P, const f
             cnt++;
         }
     };
-    RowRange r = row_range(P, cellCum, c, -1, -1, live);
+    RowRange r = range_at(P, cellCum, c, 0, capped, live);
 #pragma unroll 1
-    for (int t = 0; t < 9; t++) {
-        const int tn = t + 1;
-        const RowRange nxt = row_range(P, cellCum, c, tn % 3 - 1, tn / 3 - 1, live && tn < 9);
+    for (int t = 0; t < nRanges; t++) {
+        const RowRange nxt = range_at(P, cellCum, c, t + 1, capped, live && t + 1 < nRanges);
         const int last = r.e - 1;
         int j = r.a;
         while (__any(j < r.e)) {
