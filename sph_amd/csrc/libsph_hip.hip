@@ -64,6 +64,9 @@ struct sph_ctx {
     uint32_t* digitTotal = nullptr;
     uint32_t* sortedKeys = nullptr;   // alias into keys[] after the last build
     bool gridValid = false;
+    uint32_t* hitMask = nullptr;      // kMaskWords words per slot, written by CS_DensityPressure
+    bool maskValid = false;           // hitMask matches the current positions and grid
+    bool useHitMask = true;           // SPH_HIP_HITMASK=0 turns the hit path off
 
     int* counters = nullptr;          // SPH_CTR_COUNT ints on the device
 
@@ -136,7 +139,7 @@ void freeParticles(sph_ctx* c) {
         devFree(c->keys[k]); devFree(c->vals[k]);
     }
     devFree(c->color); devFree(c->phaseOfId); devFree(c->sid); devFree(c->perm2);
-    devFree(c->blockHist); devFree(c->aosStage); devFree(c->recStage);
+    devFree(c->blockHist); devFree(c->aosStage); devFree(c->recStage); devFree(c->hitMask);
     c->recStageCap = 0;
     if (c->pinned) (void)hipHostFree(c->pinned);
     c->pinned = nullptr; c->pinnedBytes = 0;
@@ -267,6 +270,7 @@ int clearGrid(sph_ctx* c) {
     const size_t padded = ((size_t)c->cells + 3) / 4 * 4;
     HIP_TRY(c, hipMemsetAsync(c->cumBase, 0, sizeof(int) * (padded + 4), c->stream));
     c->gridValid = false;
+    c->maskValid = false;
     return SPH_OK;
 }
 
@@ -339,23 +343,30 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false)
             return buildGrid(c);
         case SPH_K_DENSITY_PRESSURE:
             hipLaunchKernelGGL(k_density_pressure_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.rho0,
-                               s.rhoP, c->cellCum, c->counters);
+                               s.rhoP, c->cellCum, c->counters, c->useHitMask ? c->hitMask : (uint32_t*)nullptr);
+            c->maskValid = c->useHitMask && c->hitMask;
             if (c->slab)
                 hipLaunchKernelGGL(k_slab_plane_shift, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, c->sortedKeys,
                                    c->counters);
             break;
         case SPH_K_FORCE_XSPH: {
             float4* velOut = c->set[1 - c->velCur].velV;
-            hipLaunchKernelGGL(k_force_xsph_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, s.rhoP,
-                               s.acc, velOut, c->cellCum, c->counters, fused ? 1 : 0);
+            if (c->maskValid)
+                hipLaunchKernelGGL(k_force_xsph_hits, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV,
+                                   s.rhoP, s.acc, velOut, c->cellCum, c->counters, c->hitMask, fused ? 1 : 0);
+            else
+                hipLaunchKernelGGL(k_force_xsph_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV,
+                                   s.rhoP, s.acc, velOut, c->cellCum, c->counters, fused ? 1 : 0);
             c->velCur = 1 - c->velCur;
             break;
         }
         case SPH_K_VV_HALF_STEP:
+            c->maskValid = false;   // positions move
             hipLaunchKernelGGL(k_half_step, dim3(nb), dim3(kBlock), 0, c->stream, n, c->dp.dt, s.posM, s.velV, s.acc);
             break;
         case SPH_K_VV_FULL_STEP:
             if (fused) {   // + CS_BoundObs (+ CS_VelocityDamping after the last sub-step), one pass
+                c->maskValid = false;
                 hipLaunchKernelGGL(k_full_bound_damp, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, s.acc,
                                    c->counters, c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr,
                                    lastSub ? 1 : 0);
@@ -364,6 +375,7 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false)
             hipLaunchKernelGGL(k_full_step, dim3(nb), dim3(kBlock), 0, c->stream, n, c->dp.dt, s.velV, s.acc);
             break;
         case SPH_K_BOUND_OBS:
+            c->maskValid = false;
             hipLaunchKernelGGL(k_bound_obs, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, c->counters,
                                c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr);
             break;
@@ -395,6 +407,7 @@ int sph_create(sph_ctx** out, int device_id) {
     if (!c) return SPH_E_NOMEM;
     c->device = device_id;
     if (const char* tl = getenv("SPH_HIP_TIMING")) c->timingLevel = atoi(tl);
+    if (const char* hm = getenv("SPH_HIP_HITMASK")) c->useHitMask = atoi(hm) != 0;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return SPH_E_HIP;
@@ -448,6 +461,7 @@ static int allocCapacity(sph_ctx* c, int n) {
     if (!rc) rc = devAlloc(c, &c->phaseOfId, n);
     if (!rc) rc = devAlloc(c, &c->sid, n);
     if (!rc) rc = devAlloc(c, &c->perm2, n);
+    if (!rc) rc = devAlloc(c, &c->hitMask, (size_t)n * kMaskWords);
     if (!rc) rc = devAlloc(c, &c->aosStage, (size_t)n * SPH_PARTICLE_FLOATS);
     c->blockHistElems = (size_t)kRadix * ((n + kSortTile - 1) / kSortTile);
     if (!rc) rc = devAlloc(c, &c->blockHist, c->blockHistElems);
@@ -465,7 +479,7 @@ int sph_alloc_particles(sph_ctx* c, int n) {
     if (rc) return rc;
     c->n = n;
     c->cur = 0; c->velCur = 0;
-    c->gridValid = false;
+    c->gridValid = false; c->maskValid = false;
     c->havePhaseIds = false;
     // a fresh ComputeBuffer is zero-filled; give ids so download before upload is well defined
     HIP_TRY(c, hipMemsetAsync(c->aosStage, 0, (size_t)n * SPH_PARTICLE_BYTES, c->stream));
@@ -489,7 +503,7 @@ int sph_upload_particles(sph_ctx* c, const void* aos72, int n) {
     c->cur = 0; c->velCur = 0;
     hipLaunchKernelGGL(k_import_aos, dim3(blocksFor(n)), dim3(kBlock), 0, c->stream, n, c->aosStage, c->set[0], c->color);
     CHECK_LAUNCH(c);
-    c->gridValid = false;
+    c->gridValid = false; c->maskValid = false;
     c->staticDirty = true;   // SPH.cs:284-298 would overwrite the static fields on the next Update
     return SPH_OK;
 }
@@ -532,7 +546,7 @@ int sph_resize_grid(sph_ctx* c, int rx, int ry, int rz, int max_per_cell) {
         c->cellCapacity = want;
     }
     c->rx = rx; c->ry = ry; c->rz = rz; c->cap = max_per_cell; c->cells = cells;
-    c->gridValid = false;   // fresh GridCounts/GridIndices buffers (SPH.cs:344-345)
+    c->gridValid = false; c->maskValid = false;   // fresh GridCounts/GridIndices buffers (SPH.cs:344-345)
     return SPH_OK;
 }
 
@@ -543,6 +557,7 @@ int sph_set_params(sph_ctx* c, const sph_params* p) {
         return fail(c, SPH_E_INVALID, "sph_params.struct_size %u != %zu", p->struct_size, sizeof(sph_params));
     c->prm = *p;
     c->haveParams = true;
+    c->maskValid = false;   // h / grid geometry may have changed
     deriveParams(c);
     return SPH_OK;
 }
@@ -775,12 +790,12 @@ int sph_get_stream(sph_ctx* c, void** stream) {
 // ---- slab decomposition -------------------------------------------------------------------------------
 int sph_slab_configure(sph_ctx* c, int rx_global, int x_offset, int own_lo, int own_hi) {
     if (!c) return SPH_E_INVALID;
-    if (rx_global <= 0) { c->slab = false; c->gridValid = false; return SPH_OK; }
+    if (rx_global <= 0) { c->slab = false; c->gridValid = false; c->maskValid = false; return SPH_OK; }
     if (x_offset < 0 || own_lo < x_offset || own_hi < own_lo || own_hi > rx_global)
         return fail(c, SPH_E_INVALID, "bad slab: global %d, offset %d, own [%d,%d)", rx_global, x_offset, own_lo, own_hi);
     c->slab = true;
     c->rxGlobal = rx_global; c->xOffset = x_offset; c->ownLoG = own_lo; c->ownHiG = own_hi;
-    c->gridValid = false;
+    c->gridValid = false; c->maskValid = false;
     return SPH_OK;
 }
 
@@ -793,7 +808,7 @@ int sph_slab_reserve(sph_ctx* c, int capacity) {
         if (c->n > 0) return fail(c, SPH_E_STATE, "sph_slab_reserve cannot grow a populated slab (reserve before upload)");
         int rc = allocCapacity(c, capacity);
         if (rc) return rc;
-        c->n = 0; c->cur = 0; c->velCur = 0; c->gridValid = false;
+        c->n = 0; c->cur = 0; c->velCur = 0; c->gridValid = false; c->maskValid = false;
     }
     return SPH_OK;
 }
@@ -819,7 +834,7 @@ int sph_slab_upload(sph_ctx* c, const sph_slab_record* records, int n) {
         int rc = allocCapacity(c, n);
         if (rc) return rc;
     }
-    c->cur = 0; c->velCur = 0; c->gridValid = false;
+    c->cur = 0; c->velCur = 0; c->gridValid = false; c->maskValid = false;
     c->n = n;
     if (n == 0) return SPH_OK;
     int rc = ensureRecStage(c, (size_t)n);
@@ -913,7 +928,7 @@ int sph_slab_rebuild(sph_ctx* c, int keep_lo, int keep_hi, const void* dev_from_
     c->cur = 1 - c->cur;
     c->velCur = 1 - c->velCur;
     c->n = cnt;
-    c->gridValid = false;
+    c->gridValid = false; c->maskValid = false;
     *n_local = cnt;
     return SPH_OK;
 }

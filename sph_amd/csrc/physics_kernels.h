@@ -64,6 +64,7 @@ __global__ __launch_bounds__(kBlock) void k_clear(int n, float4* __restrict__ ac
 // (compute:127), hence adjacent in the sorted order: their bins are ONE slot range, read from the
 // cumulative table with two loads.  Visiting order is unchanged: z, y, then x-1, x, x+1, then id.
 struct RowRange { int a, e; };
+constexpr int kMaskWords = 16;   // hit-mask words per particle: 128 candidate groups of four
 
 #ifndef SPH_XCD_RUN
 #define SPH_XCD_RUN 16
@@ -129,7 +130,8 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
                                                                   const float* __restrict__ rho0,
                                                                   float2* __restrict__ rhoP,
                                                                   const int* __restrict__ cellCum,
-                                                                  const int* __restrict__ counters) {
+                                                                  const int* __restrict__ counters,
+                                                                  uint32_t* __restrict__ hitMask) {
     const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
     const int nRanges = capped ? 27 : 9;
     const int s = xcd_tile(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
@@ -137,13 +139,22 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
     const float4 p = posM[s];
     const int3 c = search_cell(P, p.x, p.y, p.z);
     float density = 0.0f;
+    // Hit mask for the force kernel (see k_force_xsph_hits): one bit per candidate in visiting
+    // order, rows padded to groups of four, kMaskWords words per particle; particles with more
+    // candidate groups than fit simply stop recording (the force kernel recomputes the group
+    // count from the same ranges and falls back to scanning).
+    uint32_t* const mrow = (hitMask && !capped) ? hitMask + (size_t)s * kMaskWords : nullptr;
+    uint32_t word = 0;
+    int sh = 0, wi = 0;
     // Branch-free body: a rejected candidate adds +0.0f, which leaves the running sum bit-identical
     // (every term is >= 0), so no exec-mask juggling per candidate.
-    auto visit = [&](const float4 q, int j, bool inRow) {
+    auto visit = [&](const float4 q, int j, bool inRow) -> uint32_t {
         const float rSq = dist2_exact(p.x - q.x, p.y - q.y, p.z - q.z);
         const float diff = P.h2 - rSq;
         const float term = q.w * P.poly6 * diff * diff * diff;        // compute:180
-        density += (inRow && rSq < P.h2 && j != s) ? term : 0.0f;
+        const bool hit = inRow && rSq < P.h2 && j != s;
+        density += hit ? term : 0.0f;
+        return hit ? 1u : 0u;
     };
     // Keep gathers in flight: the next row's range is fetched while this row is walked, and
     // candidates are loaded four at a time (indices clamped to the row) before any is tested.
@@ -158,13 +169,24 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
             const float4 q1 = posM[min(j + 1, last)];
             const float4 q2 = posM[min(j + 2, last)];
             const float4 q3 = posM[min(j + 3, last)];
-            visit(q0, j, true);
-            visit(q1, j + 1, j + 1 <= last);
-            visit(q2, j + 2, j + 2 <= last);
-            visit(q3, j + 3, j + 3 <= last);
+            const uint32_t h0 = visit(q0, j, true);
+            const uint32_t h1 = visit(q1, j + 1, j + 1 <= last);
+            const uint32_t h2 = visit(q2, j + 2, j + 2 <= last);
+            const uint32_t h3 = visit(q3, j + 3, j + 3 <= last);
+            if (mrow) {
+                word |= (h0 | (h1 << 1) | (h2 << 2) | (h3 << 3)) << sh;
+                sh += 4;
+                if (sh == 32) {
+                    if (wi < kMaskWords) mrow[wi] = word;
+                    wi++;
+                    word = 0;
+                    sh = 0;
+                }
+            }
         }
         r = nxt;
     }
+    if (mrow && sh != 0 && wi < kMaskWords) mrow[wi] = word;
     const float r0 = rho0[s];
     density = fmaxf(density, r0);                                          // compute:186
     const float localB = r0 * (P.soundSpeed * P.soundSpeed) / P.gamma;     // compute:189
@@ -214,64 +236,60 @@ __device__ __forceinline__ void force_pair(const DevParams& P, ForceAcc& A, cons
     A.norm += wm;                                                         // compute:277
 }
 
-// CS_ForceXSPH (compute:199-303), fast path.  Two phases per wave so that the expensive pair
-// arithmetic runs with (nearly) full lanes although only ~1/4 of the candidates are in range:
-//   scan : every lane walks its candidates, does the exact rSq < h2 test, and appends hits to its
-//          own FIFO in LDS (queue[k][thread], conflict-free);
-//   drain: when any lane's FIFO is full (wave ballot), all lanes pop their hits in order and do
-//          the pair arithmetic.  FIFO order = visiting order, so each lane still sums its
-//          neighbours in the reference's order.
+// CS_ForceXSPH (compute:199-303).  The expensive pair arithmetic must run with (nearly) full lanes
+// although only ~1/4 of the candidates are in range.  Two ways to get there:
+//
+//  scan path (force_scan): every lane walks its candidates, does the exact rSq < h2 test and appends
+//      hits to its own FIFO in LDS (queue[k][thread], conflict-free); when any lane's FIFO is nearly
+//      full (wave ballot) all lanes pop their hits in order and do the pair arithmetic.
+//  hit path (k_force_xsph_hits): CS_DensityPressure has just done the same tests on the same
+//      positions and grid, and left one bit per candidate; the lane walks the set bits only, so the
+//      rejected ~3/4 of the candidates are never loaded again.
+//
+// Either way a lane sums its neighbours in the reference's visiting order.
 constexpr int kHitQueue = 20;   // FIFO depth per lane (20 KB of LDS per workgroup)
 constexpr int kScanUnroll = 4;  // candidates loaded per lane before any is tested
 
-__global__ __launch_bounds__(kBlock) void k_force_xsph_rows(DevParams P, const float4* __restrict__ posM,
-                                                            const float4* __restrict__ velIn,
-                                                            const float2* __restrict__ rhoP,
-                                                            float4* __restrict__ acc, float4* __restrict__ velOut,
-                                                            const int* __restrict__ cellCum,
-                                                            const int* __restrict__ counters, int zeroDeadAcc) {
-    __shared__ int queue[kHitQueue][kBlock];
-    const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
+struct ForceSelf {
+    float4 p, v;
+    float densitySelf, selfTerm;
+    int s, sl;
+    bool live;
+};
+
+__device__ __forceinline__ void force_scan(const DevParams& P, ForceAcc& A, const ForceSelf& me, int3 c,
+                                           bool capped, const float4* __restrict__ posM,
+                                           const float4* __restrict__ velIn, const float2* __restrict__ rhoP,
+                                           const int* __restrict__ cellCum, int (*queue)[kBlock]) {
     const int nRanges = capped ? 27 : 9;
-    const int s = xcd_tile(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
-    const bool valid = s < P.n;
-    const int sl = valid ? s : 0;
-    const float4 p = posM[sl];
-    const float4 v = velIn[sl];
-    const float2 dp = rhoP[sl];
-    const float densitySelf = dp.x;
-    const bool live = valid && !(densitySelf < 1e-6f);                     // compute:207-211
-    const float selfTerm = dp.y / (densitySelf * densitySelf);
-    ForceAcc A{0.0f, P.gravity * densitySelf, 0.0f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // compute:219
-    const int3 c = search_cell(P, p.x, p.y, p.z);
     int cnt = 0;
     auto drain = [&]() {
         // two pairs per trip: six gathers in flight before the arithmetic starts
 #pragma unroll 1
         for (int k = 0; k < kHitQueue; k += 2) {
             if (!__any(k < cnt)) break;
-            const int j0 = (k < cnt) ? queue[k][threadIdx.x] : sl;
-            const int j1 = (k + 1 < cnt) ? queue[k + 1][threadIdx.x] : sl;
+            const int j0 = (k < cnt) ? queue[k][threadIdx.x] : me.sl;
+            const int j1 = (k + 1 < cnt) ? queue[k + 1][threadIdx.x] : me.sl;
             const float4 q0 = posM[j0], u0 = velIn[j0];
             const float2 o0 = rhoP[j0];
             const float4 q1 = posM[j1], u1 = velIn[j1];
             const float2 o1 = rhoP[j1];
-            if (k < cnt) force_pair(P, A, p, v, densitySelf, selfTerm, q0, u0, o0);
-            if (k + 1 < cnt) force_pair(P, A, p, v, densitySelf, selfTerm, q1, u1, o1);
+            if (k < cnt) force_pair(P, A, me.p, me.v, me.densitySelf, me.selfTerm, q0, u0, o0);
+            if (k + 1 < cnt) force_pair(P, A, me.p, me.v, me.densitySelf, me.selfTerm, q1, u1, o1);
         }
         cnt = 0;
     };
     auto test = [&](const float4 q, int j) {
-        const float rSq = dist2_exact(p.x - q.x, p.y - q.y, p.z - q.z);
-        if (rSq < P.h2 && j != s) {
+        const float rSq = dist2_exact(me.p.x - q.x, me.p.y - q.y, me.p.z - q.z);
+        if (rSq < P.h2 && j != me.s) {
             queue[cnt][threadIdx.x] = j;
             cnt++;
         }
     };
-    RowRange r = range_at(P, cellCum, c, 0, capped, live);
+    RowRange r = range_at(P, cellCum, c, 0, capped, me.live);
 #pragma unroll 1
     for (int t = 0; t < nRanges; t++) {
-        const RowRange nxt = range_at(P, cellCum, c, t + 1, capped, live && t + 1 < nRanges);
+        const RowRange nxt = range_at(P, cellCum, c, t + 1, capped, me.live && t + 1 < nRanges);
         const int last = r.e - 1;
         int j = r.a;
         while (__any(j < r.e)) {
@@ -291,9 +309,31 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_rows(DevParams P, const f
         r = nxt;
     }
     drain();
-    if (!valid) return;
-    if (!live) {
-        velOut[s] = v;
+}
+
+__device__ __forceinline__ ForceSelf force_load_self(const DevParams& P, int s, const float4* __restrict__ posM,
+                                                     const float4* __restrict__ velIn,
+                                                     const float2* __restrict__ rhoP) {
+    ForceSelf me;
+    me.s = s;
+    const bool valid = s < P.n;
+    me.sl = valid ? s : 0;
+    me.p = posM[me.sl];
+    me.v = velIn[me.sl];
+    const float2 dp = rhoP[me.sl];
+    me.densitySelf = dp.x;
+    me.live = valid && !(me.densitySelf < 1e-6f);                          // compute:207-211
+    me.selfTerm = dp.y / (me.densitySelf * me.densitySelf);
+    return me;
+}
+
+__device__ __forceinline__ void force_finish(const DevParams& P, ForceAcc& A, const ForceSelf& me,
+                                             float4* __restrict__ acc, float4* __restrict__ velOut,
+                                             int zeroDeadAcc) {
+    const int s = me.s;
+    if (s >= P.n) return;
+    if (!me.live) {
+        velOut[s] = me.v;
         if (zeroDeadAcc) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);   // what the elided CS_Clear would have left
         return;
     }
@@ -305,15 +345,111 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_rows(DevParams P, const f
             const float st = -P.sigma * curvature / gradMag;
             A.fx += st * A.cgx; A.fy += st * A.cgy; A.fz += st * A.cgz;
         }
-        const float invD = 1.0f / densitySelf;
+        const float invD = 1.0f / me.densitySelf;
         acc[s] = make_float4(A.fx * invD, A.fy * invD, A.fz * invD, 0.f);            // compute:293
-        float4 vo = v;
+        float4 vo = me.v;
         if (A.norm > 1e-6f) {                                                        // compute:296-300
             const float sc = P.xsphEps / A.norm;
             vo.x += A.vcx * sc; vo.y += A.vcy * sc; vo.z += A.vcz * sc;
         }
         velOut[s] = vo;
     }
+}
+
+// Scan path only: valid for any state (used when no fresh hit mask exists).
+__global__ __launch_bounds__(kBlock) void k_force_xsph_rows(DevParams P, const float4* __restrict__ posM,
+                                                            const float4* __restrict__ velIn,
+                                                            const float2* __restrict__ rhoP,
+                                                            float4* __restrict__ acc, float4* __restrict__ velOut,
+                                                            const int* __restrict__ cellCum,
+                                                            const int* __restrict__ counters, int zeroDeadAcc) {
+    __shared__ int queue[kHitQueue][kBlock];
+    const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
+    const int s = xcd_tile(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+    const ForceSelf me = force_load_self(P, s, posM, velIn, rhoP);
+    ForceAcc A{0.0f, P.gravity * me.densitySelf, 0.0f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // compute:219
+    const int3 c = search_cell(P, me.p.x, me.p.y, me.p.z);
+    force_scan(P, A, me, c, capped, posM, velIn, rhoP, cellCum, queue);
+    force_finish(P, A, me, acc, velOut, zeroDeadAcc);
+}
+
+// Hit path.  PRECONDITION (kept by the host, libsph_hip.hip `maskValid`): hitMask was written by
+// k_density_pressure_rows on exactly these positions and this grid.  A wave falls back to the scan
+// path if a bin overflowed (27 capped ranges, no mask) or any of its particles has more candidate
+// groups than the mask holds.
+__global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const float4* __restrict__ posM,
+                                                            const float4* __restrict__ velIn,
+                                                            const float2* __restrict__ rhoP,
+                                                            float4* __restrict__ acc, float4* __restrict__ velOut,
+                                                            const int* __restrict__ cellCum,
+                                                            const int* __restrict__ counters,
+                                                            const uint32_t* __restrict__ hitMask, int zeroDeadAcc) {
+    static_assert(kHitQueue >= 18, "row table shares the FIFO's LDS");
+    __shared__ int lds[kHitQueue][kBlock];
+    const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
+    const int s = xcd_tile(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+    const ForceSelf me = force_load_self(P, s, posM, velIn, rhoP);
+    ForceAcc A{0.0f, P.gravity * me.densitySelf, 0.0f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // compute:219
+    const int3 c = search_cell(P, me.p.x, me.p.y, me.p.z);
+    const int tid = threadIdx.x;
+    int totalNib = 0;
+    if (!capped) {
+        // row table in LDS: rows 0..8 = first slot of the row, rows 9..17 = running count of
+        // candidate groups up to and including the row (the mask's bit layout)
+        RowRange rr[9];
+#pragma unroll
+        for (int t = 0; t < 9; t++) rr[t] = row_range(P, cellCum, c, t % 3 - 1, t / 3 - 1, me.live);
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            lds[t][tid] = rr[t].a;
+            totalNib += (rr[t].e - rr[t].a + 3) >> 2;
+            lds[9 + t][tid] = totalNib;
+        }
+    }
+    if (capped || __any(totalNib > kMaskWords * 8)) {
+        force_scan(P, A, me, c, capped, posM, velIn, rhoP, cellCum, lds);
+    } else {
+        const uint32_t* __restrict__ mrow = hitMask + (size_t)me.sl * kMaskWords;
+        const int nWords = (totalNib + 7) >> 3;          // 0 for dead lanes
+        int wi = 0;
+        uint32_t w = 0;
+        uint32_t wnext = nWords > 0 ? mrow[0] : 0u;
+        int t = 0, rowA = lds[0][tid], nibStart = 0, nibEnd = lds[9][tid];
+        const int nLast = P.n - 1;
+        auto pop = [&](int& j) -> bool {
+            while (w == 0 && wi < nWords) {
+                w = wnext;
+                wi++;
+                wnext = (wi < nWords) ? mrow[wi] : 0u;
+            }
+            if (w == 0) { j = me.sl; return false; }
+            const int B = ((wi - 1) << 5) + __builtin_ctz(w);
+            w &= w - 1;
+            const int nb = B >> 2;
+            while (nb >= nibEnd && t < 8) {
+                t++;
+                rowA = lds[t][tid];
+                nibStart = nibEnd;
+                nibEnd = lds[9 + t][tid];
+            }
+            j = min(rowA + ((nb - nibStart) << 2) + (B & 3), nLast);
+            return true;
+        };
+#pragma unroll 1
+        for (;;) {
+            int j0, j1;
+            const bool h0 = pop(j0);
+            const bool h1 = pop(j1);
+            if (!__any(h0)) break;
+            const float4 q0 = posM[j0], u0 = velIn[j0];
+            const float2 o0 = rhoP[j0];
+            const float4 q1 = posM[j1], u1 = velIn[j1];
+            const float2 o1 = rhoP[j1];
+            if (h0) force_pair(P, A, me.p, me.v, me.densitySelf, me.selfTerm, q0, u0, o0);
+            if (h1) force_pair(P, A, me.p, me.v, me.densitySelf, me.selfTerm, q1, u1, o1);
+        }
+    }
+    force_finish(P, A, me, acc, velOut, zeroDeadAcc);
 }
 
 // CS_VvHalfStep (compute:309-319)
