@@ -59,9 +59,6 @@ struct sph_ctx {
     uint32_t* vals[2] = {nullptr, nullptr};
     uint32_t* sid = nullptr;
     uint32_t* perm2 = nullptr;
-    uint32_t* blockHist = nullptr;
-    size_t blockHistElems = 0;
-    uint32_t* digitTotal = nullptr;
     uint32_t* sortedKeys = nullptr;   // alias into keys[] after the last build
     bool gridValid = false;
     uint32_t* hitMask = nullptr;      // kMaskWords words per slot, written by CS_DensityPressure
@@ -139,11 +136,11 @@ void freeParticles(sph_ctx* c) {
         devFree(c->keys[k]); devFree(c->vals[k]);
     }
     devFree(c->color); devFree(c->phaseOfId); devFree(c->sid); devFree(c->perm2);
-    devFree(c->blockHist); devFree(c->aosStage); devFree(c->recStage); devFree(c->hitMask);
+    devFree(c->aosStage); devFree(c->recStage); devFree(c->hitMask);
     c->recStageCap = 0;
     if (c->pinned) (void)hipHostFree(c->pinned);
     c->pinned = nullptr; c->pinnedBytes = 0;
-    c->capacity = 0; c->n = 0; c->blockHistElems = 0;
+    c->capacity = 0; c->n = 0;
 }
 
 void freeGrid(sph_ctx* c) {
@@ -274,7 +271,7 @@ int clearGrid(sph_ctx* c) {
     return SPH_OK;
 }
 
-// CS_BuildGrid (compute:117-136): hash -> stable radix sort by cell -> ranges -> id order inside
+// CS_BuildGrid (compute:117-136): hash + counting sort by cell over the cumulative table -> id order inside
 // each cell -> physical reorder of the state into (cell, id) order.
 int buildGrid(sph_ctx* c) {
     const int n = c->n;
@@ -283,38 +280,23 @@ int buildGrid(sph_ctx* c) {
     if (rc) return rc;
     HIP_TRY(c, hipMemsetAsync(c->counters + SPH_CTR_BIN_OVERFLOW, 0, 3 * sizeof(int), c->stream));
     StateSet src = curSet(c);
-    hipLaunchKernelGGL(k_hash, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, src.posM, c->keys[0], c->counters);
+    // keys[0] = cell per old slot, vals[0] = arrival number; keys[1] / vals[1] / sid = key, source slot
+    // and id per bucket slot
+    hipLaunchKernelGGL(k_hash_count, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, src.posM, c->keys[0], c->vals[0],
+                       c->cumT, c->counters);
     CHECK_LAUNCH(c);
-
-    int bits = 1;
-    while ((1ll << bits) < c->cells) bits++;
-    const int passes = (bits + 7) / 8;
-    const int sortBlocks = (n + kSortTile - 1) / kSortTile;
-    int in = 0;
-    for (int p = 0; p < passes; p++) {
-        const int shift = 8 * p;
-        hipLaunchKernelGGL(k_sort_hist, dim3(sortBlocks), dim3(kBlock), 0, c->stream, c->keys[in], n, shift,
-                           c->blockHist, sortBlocks);
-        hipLaunchKernelGGL(k_sort_scan_rows, dim3(kRadix), dim3(kBlock), 0, c->stream, c->blockHist, sortBlocks,
-                           c->digitTotal);
-        hipLaunchKernelGGL(k_sort_scatter, dim3(sortBlocks), dim3(kBlock), 0, c->stream, c->keys[in],
-                           p == 0 ? (const uint32_t*)nullptr : c->vals[in], c->keys[1 - in], c->vals[1 - in], n,
-                           shift, c->blockHist, sortBlocks, c->digitTotal);
-        CHECK_LAUNCH(c);
-        in = 1 - in;
-    }
-    c->sortedKeys = c->keys[in];
-    uint32_t* perm = c->vals[in];
-    hipLaunchKernelGGL(k_cell_marks, dim3(nb), dim3(kBlock), 0, c->stream, c->sortedKeys, n, c->cumT);
-    {   // cumulative cell table for the 3-cells-per-row search
+    {   // counts -> cumulative cell table
         const long long cells4 = (c->cells + 3) / 4;
         const int cb = (int)((c->cells + kScanTile - 1) / kScanTile);
-        hipLaunchKernelGGL(k_cum_block_max, dim3(cb), dim3(kBlock), 0, c->stream, (const int4*)c->cumT, cells4,
+        hipLaunchKernelGGL(k_cum_block_sum, dim3(cb), dim3(kBlock), 0, c->stream, (const int4*)c->cumT, cells4,
                            c->cumBlocks);
         hipLaunchKernelGGL(k_cum_scan_blocks, dim3(1), dim3(kBlock), 0, c->stream, c->cumBlocks, cb);
         hipLaunchKernelGGL(k_cum_write, dim3(cb), dim3(kBlock), 0, c->stream, (int4*)c->cumT, cells4, c->cumBlocks);
     }
-    hipLaunchKernelGGL(k_gather_ids, dim3(nb), dim3(kBlock), 0, c->stream, perm, src.origId, n, c->sid);
+    c->sortedKeys = c->keys[1];
+    uint32_t* perm = c->vals[1];
+    hipLaunchKernelGGL(k_place, dim3(nb), dim3(kBlock), 0, c->stream, n, c->keys[0], c->vals[0], src.origId,
+                       c->cellCum, c->sortedKeys, perm, c->sid);
     StateSet dst = c->set[1 - c->cur];
     // velocities of the new order go to the set that does NOT hold the current ones
     dst.velV = c->set[1 - c->velCur].velV;
@@ -415,7 +397,6 @@ int sph_create(sph_ctx** out, int device_id) {
     for (int r = 0; r < kTimingRing; r++)
         for (int k = 0; k < kNumEvents; k++) (void)hipEventCreate(&c->ev[r][k]);
     if (hipMalloc((void**)&c->counters, SPH_CTR_COUNT * sizeof(int)) != hipSuccess ||
-        hipMalloc((void**)&c->digitTotal, kRadix * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->slabCounts, 4 * sizeof(int)) != hipSuccess ||
         hipMemsetAsync(c->counters, 0, SPH_CTR_COUNT * sizeof(int), c->stream) != hipSuccess) {
         sph_destroy(c);
@@ -432,7 +413,6 @@ int sph_destroy(sph_ctx* c) {
     freeParticles(c);
     freeGrid(c);
     devFree(c->counters);
-    devFree(c->digitTotal);
     devFree(c->slabCounts);
     devFree(c->phaseTableDev);
     for (int r = 0; r < kTimingRing; r++)
@@ -463,8 +443,6 @@ static int allocCapacity(sph_ctx* c, int n) {
     if (!rc) rc = devAlloc(c, &c->perm2, n);
     if (!rc) rc = devAlloc(c, &c->hitMask, (size_t)n * kMaskWords);
     if (!rc) rc = devAlloc(c, &c->aosStage, (size_t)n * SPH_PARTICLE_FLOATS);
-    c->blockHistElems = (size_t)kRadix * ((n + kSortTile - 1) / kSortTile);
-    if (!rc) rc = devAlloc(c, &c->blockHist, c->blockHistElems);
     if (rc) { freeParticles(c); return rc; }
     c->capacity = n;
     return SPH_OK;
