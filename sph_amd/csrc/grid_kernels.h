@@ -188,6 +188,26 @@ __global__ __launch_bounds__(kBlock) void k_permute_state(int n, const uint32_t*
     dst.rho0[k] = src.rho0[s];
 }
 
+// sph_step_frame's variant: reorder + the first CS_VvHalfStep (compute:309-319) in one pass.  The
+// half step is the same two statements as k_half_step, so positions and velocities are
+// bit-identical to permute-then-half-step.  Acceleration is consumed here and density / pressure
+// are dead (the neighbour kernels overwrite all three before anything reads them), so they are
+// not carried over: 56 B read + 36 B written per particle instead of 132 + 80.
+__global__ __launch_bounds__(kBlock) void k_permute_half(int n, float dt, const uint32_t* __restrict__ perm2,
+                                                         StateSet src, StateSet dst) {
+    int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n) return;
+    uint32_t s = perm2[k];
+    float4 p = src.posM[s], v = src.velV[s];
+    const float4 a = src.acc[s];
+    const float hdt = 0.5f * dt;
+    v.x += hdt * a.x; v.y += hdt * a.y; v.z += hdt * a.z;
+    p.x += v.x * dt; p.y += v.y * dt; p.z += v.z * dt;
+    dst.posM[k] = p;
+    dst.velV[k] = v;
+    dst.rho0[k] = src.rho0[s];
+}
+
 // cell_of_particle export: keys are per slot, the caller wants them per id
 __global__ __launch_bounds__(kBlock) void k_scatter_by_id(int n, const uint32_t* __restrict__ in,
                                                           const uint32_t* __restrict__ origId,

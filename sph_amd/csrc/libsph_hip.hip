@@ -273,7 +273,7 @@ int clearGrid(sph_ctx* c) {
 
 // CS_BuildGrid (compute:117-136): hash + counting sort by cell over the cumulative table -> id order inside
 // each cell -> physical reorder of the state into (cell, id) order.
-int buildGrid(sph_ctx* c) {
+int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
     const int n = c->n;
     const int nb = blocksFor(n);
     int rc = clearGrid(c);
@@ -302,7 +302,10 @@ int buildGrid(sph_ctx* c) {
     dst.velV = c->set[1 - c->velCur].velV;
     hipLaunchKernelGGL(k_rank_in_cell, dim3(nb), dim3(kBlock), 0, c->stream, c->sortedKeys, perm, c->sid, n, c->cap,
                        c->cellCum, c->cellCum + 1, c->perm2, dst.origId, c->counters);
-    hipLaunchKernelGGL(k_permute_state, dim3(nb), dim3(kBlock), 0, c->stream, n, c->perm2, src, dst);
+    if (fuseHalfStep)   // sph_step_frame: reorder + first CS_VvHalfStep in one pass
+        hipLaunchKernelGGL(k_permute_half, dim3(nb), dim3(kBlock), 0, c->stream, n, c->dp.dt, c->perm2, src, dst);
+    else
+        hipLaunchKernelGGL(k_permute_state, dim3(nb), dim3(kBlock), 0, c->stream, n, c->perm2, src, dst);
     CHECK_LAUNCH(c);
     c->cur = 1 - c->cur;
     c->velCur = 1 - c->velCur;
@@ -612,17 +615,19 @@ int sph_step_frame(sph_ctx* c, int sub_steps, float time_step) {
     hipEvent_t* ev = c->ev[slot];
     const int tl = c->timingLevel;
     if (tl >= 1) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-    // SPH.cs:201 + 204: CS_ClearGrid is the first step of the grid build here
-    if ((rc = dispatchKernel(c, SPH_K_BUILD_GRID))) return rc;
-    if (tl >= 2) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     sph_set_delta_time(c, time_step / (float)sub_steps);                    // SPH.cs:207-208
+    // SPH.cs:201 + 204: CS_ClearGrid is the first step of the grid build here; the state reorder at
+    // its end also does the first sub-step's CS_VvHalfStep
+    c->dp.n = c->n;
+    if ((rc = buildGrid(c, true))) return rc;
+    if (tl >= 2) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     // SPH.cs:210-222 with the dead and the purely streaming stages folded together (bit-identical
     // results): CS_Clear is elided (density/pressure/acceleration are fully overwritten by the two
     // neighbour kernels; the force kernel zeroes the acceleration of the particles it skips), and
     // CS_VvFullStep + CS_BoundObs + (after the last sub-step) CS_VelocityDamping are one pass.
     for (int s = 0; s < sub_steps; s++) {                                   // SPH.cs:210-219
         const bool last = s == sub_steps - 1;
-        if ((rc = dispatchKernel(c, SPH_K_VV_HALF_STEP))) return rc;
+        if (s > 0 && (rc = dispatchKernel(c, SPH_K_VV_HALF_STEP))) return rc;
         if (last && tl >= 1) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
         if ((rc = dispatchKernel(c, SPH_K_DENSITY_PRESSURE))) return rc;
         if (last && tl >= 1) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
