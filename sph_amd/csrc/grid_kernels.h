@@ -31,8 +31,7 @@ __device__ __forceinline__ int3 cell_unclamped(const DevParams& P, float x, floa
 //   k_rank_in_cell (below) then orders every cell by particle id, which removes the arbitrariness:
 //                  the result is the unique (cell, id) order whatever order the atomics ran in.
 // Particles are still in last frame's (cell, id) order when this runs, so consecutive lanes hit the
-// same or neighbouring table entries (measured: 1 M returning atomics on the 3.5 M-cell table in
-// ~9 us; 40 us for a random order, which happens once after an upload).
+// same or neighbouring table entries; runs of equal cells inside a wave share one atomic.
 // Kernels index the table through cellCum = T - 1 (cellCum[c] = #particles with cell < c): the bin
 // of cell c is [cellCum[c], cellCum[c+1]) and any run of consecutive cells [c0, c1] is the single
 // slot range [cellCum[c0], cellCum[c1+1]) -- what the 3-cells-per-row search reads with two loads.
@@ -40,7 +39,9 @@ __global__ __launch_bounds__(kBlock) void k_hash_count(DevParams P, const float4
                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ arrival,
                                                        int* __restrict__ T, int* __restrict__ counters) {
     int s = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     bool oog = false;
+    uint32_t key = 0xFFFFFFFFu;                          // lanes past the end: a run of their own, no atomic
     if (s < P.n) {
         float4 p = posM[s];
         int3 c = cell_unclamped(P, p.x, p.y, p.z);
@@ -49,12 +50,23 @@ __global__ __launch_bounds__(kBlock) void k_hash_count(DevParams P, const float4
         x = min(max(x, 0), P.rx - 1);                    // memory safety only: a slab never holds such a particle
         int y = min(max(c.y, 0), P.ry - 1);
         int z = min(max(c.z, 0), P.rz - 1);
-        const uint32_t key = (uint32_t)(x + y * P.rx + z * P.rx * P.ry);
+        key = (uint32_t)(x + y * P.rx + z * P.rx * P.ry);
         keys[s] = key;
-        arrival[s] = (uint32_t)atomicAdd(&T[key], 1);
     }
+    // Wave-aggregated: consecutive lanes with the same cell (the usual case -- the particles are
+    // still in last frame's cell order) share ONE atomic, issued by the first lane of the run.
+    const uint32_t prev = __shfl_up(key, 1);
+    const bool head = lane == 0 || prev != key;
+    const unsigned long long heads = __ballot(head);
+    const int headLane = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull));      // bit 0 is always set
+    const unsigned long long above = (headLane == 63) ? 0ull : heads & ~((2ull << headLane) - 1ull);
+    const int runLen = (above ? __builtin_ctzll(above) : 64) - headLane;
+    int base = 0;
+    if (head && key != 0xFFFFFFFFu) base = atomicAdd(&T[key], runLen);
+    base = __shfl(base, headLane);
+    if (s < P.n) arrival[s] = (uint32_t)(base + (lane - headLane));
     unsigned long long m = __ballot(oog);
-    if (m && (threadIdx.x & 63) == 0) atomicAdd(&counters[SPH_CTR_OUT_OF_GRID], __popcll(m));
+    if (m && lane == 0) atomicAdd(&counters[SPH_CTR_OUT_OF_GRID], __popcll(m));
 }
 
 constexpr int kScanVec = 4;                              // int4 per thread per round

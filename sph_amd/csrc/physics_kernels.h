@@ -435,18 +435,34 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
             j = min(rowA + ((nb - nibStart) << 2) + (B & 3), nLast);
             return true;
         };
+        // Software-pipelined, two pairs per stage: the six gathers of the next two hits are issued
+        // before the arithmetic of the current two starts.
+        struct Stage {
+            float4 q0, u0, q1, u1;
+            float2 o0, o1;
+            bool h0, h1;
+        };
+        auto fetch = [&](Stage& S) {
+            int j0, j1;
+            S.h0 = pop(j0);
+            S.h1 = pop(j1);
+            S.q0 = posM[j0]; S.u0 = velIn[j0]; S.o0 = rhoP[j0];
+            S.q1 = posM[j1]; S.u1 = velIn[j1]; S.o1 = rhoP[j1];
+        };
+        auto compute = [&](const Stage& S) {
+            if (S.h0) force_pair(P, A, me.p, me.v, me.densitySelf, me.selfTerm, S.q0, S.u0, S.o0);
+            if (S.h1) force_pair(P, A, me.p, me.v, me.densitySelf, me.selfTerm, S.q1, S.u1, S.o1);
+        };
+        Stage SA, SB;
+        fetch(SA);
 #pragma unroll 1
         for (;;) {
-            int j0, j1;
-            const bool h0 = pop(j0);
-            const bool h1 = pop(j1);
-            if (!__any(h0)) break;
-            const float4 q0 = posM[j0], u0 = velIn[j0];
-            const float2 o0 = rhoP[j0];
-            const float4 q1 = posM[j1], u1 = velIn[j1];
-            const float2 o1 = rhoP[j1];
-            if (h0) force_pair(P, A, me.p, me.v, me.densitySelf, me.selfTerm, q0, u0, o0);
-            if (h1) force_pair(P, A, me.p, me.v, me.densitySelf, me.selfTerm, q1, u1, o1);
+            if (!__any(SA.h0)) break;
+            fetch(SB);
+            compute(SA);
+            if (!__any(SB.h0)) break;
+            fetch(SA);
+            compute(SB);
         }
     }
     force_finish(P, A, me, acc, velOut, zeroDeadAcc);
