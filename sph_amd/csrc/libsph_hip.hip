@@ -428,10 +428,11 @@ int sph_destroy(sph_ctx* c) {
 
 static int allocCapacity(sph_ctx* c, int n) {
     if (n <= c->capacity) return SPH_OK;
+    if (n > kMaxParticles) return fail(c, SPH_E_INVALID, "particle capacity %d exceeds the limit of %d", n, kMaxParticles);
     freeParticles(c);
     int rc = 0;
     for (int k = 0; k < 2 && !rc; k++) {
-        rc = devAlloc(c, &c->set[k].posM, n);
+        rc = devAlloc(c, &c->set[k].posM, (size_t)n + kSlotPad);
         if (!rc) rc = devAlloc(c, &c->set[k].velV, n);
         if (!rc) rc = devAlloc(c, &c->set[k].acc, n);
         if (!rc) rc = devAlloc(c, &c->set[k].rhoP, n);

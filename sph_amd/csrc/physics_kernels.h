@@ -146,33 +146,44 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
     uint32_t* const mrow = (hitMask && !capped) ? hitMask + (size_t)s * kMaskWords : nullptr;
     uint32_t word = 0;
     int sh = 0, wi = 0;
-    // Branch-free body: a rejected candidate adds +0.0f, which leaves the running sum bit-identical
-    // (every term is >= 0), so no exec-mask juggling per candidate.
-    auto visit = [&](const float4 q, int j, bool inRow) -> uint32_t {
-        const float rSq = dist2_exact(p.x - q.x, p.y - q.y, p.z - q.z);
-        const float diff = P.h2 - rSq;
-        const float term = q.w * P.poly6 * diff * diff * diff;        // compute:180
-        const bool hit = inRow && rSq < P.h2 && j != s;
-        density += hit ? term : 0.0f;
-        return hit ? 1u : 0u;
-    };
     // Keep gathers in flight: the next row's range is fetched while this row is walked, and
-    // candidates are loaded four at a time (indices clamped to the row) before any is tested.
-    // Order of the sum is unchanged.
+    // candidates are loaded four at a time before any is tested.  Order of the sum is unchanged.
+    // (Packed v_pk_*_f32 arithmetic was tried here: on gfx950 a packed op issues at half the rate
+    // of a plain one -- scripts/experiments/valu_rate.hip -- so it only adds register shuffles; the
+    // TU is built with -fno-slp-vectorize for the same reason.)
     RowRange r = range_at(P, cellCum, c, 0, capped, true);
 #pragma unroll 1
     for (int t = 0; t < nRanges; t++) {
         const RowRange nxt = range_at(P, cellCum, c, t + 1, capped, t + 1 < nRanges);
         const int last = r.e - 1;
         for (int j = r.a; j < r.e; j += 4) {
-            const float4 q0 = posM[j];
-            const float4 q1 = posM[min(j + 1, last)];
-            const float4 q2 = posM[min(j + 2, last)];
-            const float4 q3 = posM[min(j + 3, last)];
-            const uint32_t h0 = visit(q0, j, true);
-            const uint32_t h1 = visit(q1, j + 1, j + 1 <= last);
-            const uint32_t h2 = visit(q2, j + 2, j + 2 <= last);
-            const uint32_t h3 = visit(q3, j + 3, j + 3 <= last);
+            // one 32-bit byte offset + immediates: slots past the row's end are loaded (the arrays
+            // are padded by kSlotPad entries) and rejected by the predicates below
+            const char* const qb = (const char*)posM + ((uint32_t)j << 4);
+            const float4 q0 = *(const float4*)qb;
+            const float4 q1 = *(const float4*)(qb + 16);
+            const float4 q2 = *(const float4*)(qb + 32);
+            const float4 q3 = *(const float4*)(qb + 48);
+            const float rs0 = dist2_exact(p.x - q0.x, p.y - q0.y, p.z - q0.z);
+            const float rs1 = dist2_exact(p.x - q1.x, p.y - q1.y, p.z - q1.z);
+            const float rs2 = dist2_exact(p.x - q2.x, p.y - q2.y, p.z - q2.z);
+            const float rs3 = dist2_exact(p.x - q3.x, p.y - q3.y, p.z - q3.z);
+            const float d0 = P.h2 - rs0, d1 = P.h2 - rs1, d2 = P.h2 - rs2, d3 = P.h2 - rs3;
+            const float t0 = q0.w * P.poly6 * d0 * d0 * d0;              // compute:180, left to right
+            const float t1 = q1.w * P.poly6 * d1 * d1 * d1;
+            const float t2 = q2.w * P.poly6 * d2 * d2 * d2;
+            const float t3 = q3.w * P.poly6 * d3 * d3 * d3;
+            const bool k0 = rs0 < P.h2 && j != s;
+            const bool k1 = j + 1 <= last && rs1 < P.h2 && j + 1 != s;
+            const bool k2 = j + 2 <= last && rs2 < P.h2 && j + 2 != s;
+            const bool k3 = j + 3 <= last && rs3 < P.h2 && j + 3 != s;
+            // branch-free: a rejected candidate adds +0.0f, which leaves the running sum
+            // bit-identical (every term is >= 0), so no exec-mask juggling per candidate
+            density += k0 ? t0 : 0.0f;
+            density += k1 ? t1 : 0.0f;
+            density += k2 ? t2 : 0.0f;
+            density += k3 ? t3 : 0.0f;
+            const uint32_t h0 = k0, h1 = k1, h2 = k2, h3 = k3;
             if (mrow) {
                 word |= (h0 | (h1 << 1) | (h2 << 2) | (h3 << 3)) << sh;
                 sh += 4;

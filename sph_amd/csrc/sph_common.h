@@ -9,6 +9,11 @@ namespace sph {
 
 constexpr int kBlock = 256;        // threads per workgroup = 4 wave64
 constexpr int kWave = 64;
+// The density kernel loads candidates four slots at a time from a 32-bit byte offset without
+// clamping to the row's end: posM is allocated kSlotPad entries longer than the particle capacity,
+// and capacities stay below 2^28 particles (16-byte entries, 4 GiB of offsets).
+constexpr int kSlotPad = 4;
+constexpr int kMaxParticles = (1 << 28) - 8;
 
 // Kernel-side copy of the cbuffer (compute:47-81) plus the O4 derived constants, passed by
 // value as a kernel argument (lands in SGPRs / the kernarg segment; no constant-buffer upload).
