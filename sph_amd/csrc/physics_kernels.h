@@ -349,19 +349,21 @@ __device__ __forceinline__ void force_finish(const DevParams& P, ForceAcc& A, co
         return;
     }
     {
-#pragma clang fp contract(fast)
+        // explicit operations, contraction off: this tail is inlined into two kernels and a particle
+        // must get the same bits whichever of them handles it
+#pragma clang fp contract(off)
         const float gradMag = sqrtf((A.cgx * A.cgx + A.cgy * A.cgy) + A.cgz * A.cgz);   // compute:285
         if (gradMag > P.stThreshold) {
             const float curvature = A.cl / (gradMag + 1e-6f);
             const float st = -P.sigma * curvature / gradMag;
-            A.fx += st * A.cgx; A.fy += st * A.cgy; A.fz += st * A.cgz;
+            A.fx = fmaf(st, A.cgx, A.fx); A.fy = fmaf(st, A.cgy, A.fy); A.fz = fmaf(st, A.cgz, A.fz);
         }
         const float invD = 1.0f / me.densitySelf;
         acc[s] = make_float4(A.fx * invD, A.fy * invD, A.fz * invD, 0.f);            // compute:293
         float4 vo = me.v;
         if (A.norm > 1e-6f) {                                                        // compute:296-300
             const float sc = P.xsphEps / A.norm;
-            vo.x += A.vcx * sc; vo.y += A.vcy * sc; vo.z += A.vcz * sc;
+            vo.x = fmaf(A.vcx, sc, vo.x); vo.y = fmaf(A.vcy, sc, vo.y); vo.z = fmaf(A.vcz, sc, vo.z);
         }
         velOut[s] = vo;
     }

@@ -1,0 +1,88 @@
+"""The two routes through CS_ForceXSPH in libsph_hip -- walking the hit mask left by
+CS_DensityPressure (k_force_xsph_hits) and re-testing every candidate (k_force_xsph_rows / the
+per-wave fallback) -- must give the same bits, and both must match the oracle.  -m gpu."""
+import os
+
+import numpy as np
+import pytest
+
+from sph_amd import abi, scenes
+from sph_amd.host import SPH, Scene, SpawnBox, Time
+from tests.util import assert_fields_close, assert_neighbors_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def engine_without_hit_mask():
+    os.environ["SPH_HIP_HITMASK"] = "0"          # read once, in sph_create
+    try:
+        return abi.Engine(0)
+    finally:
+        del os.environ["SPH_HIP_HITMASK"]
+
+
+def crowded(e, n=3000, cap=500):
+    """~90 particles per cell, bins not capped: every particle has > 512 candidates, more than the
+    hit mask holds, so k_force_xsph_hits takes its per-wave fallback."""
+    boxes = [SpawnBox(n, (0.8, 0.8, 0.8), 20, 0.1, 0.2, position=(0.0, 5.0, 0.0))]
+    f = dict(scenes.SCENE_COMMON)
+    f.update(gridResolution=40, maxParticlesPerCell=cap)
+    sph = SPH(e, **f, surfaceTensionCoefficient=0.1, xsphEpsilon=0.3, spawnBoxes=boxes)
+    return Scene(sph, Time(), [])
+
+
+@pytest.mark.parametrize("step_frame", [False, True])
+def test_hit_path_and_scan_path_agree_bitwise(step_frame):
+    a, b = abi.Engine(0), engine_without_hit_mask()
+    sa, sb = scenes.unity_scene(a, which=4, scale_count=0.05), scenes.unity_scene(b, which=4, scale_count=0.05)
+    for s in (sa, sb):
+        s.sph.use_step_frame = step_frame
+        s.start()
+    for f in range(6):
+        sa.frame(); sb.frame()
+        pa, pb = a.download_particles(), b.download_particles()
+        assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32)), f"frame {f}"
+    a.destroy(); b.destroy()
+
+
+def test_crowded_particles_fall_back_and_match_the_oracle():
+    from oracle.ora import Oracle
+    eng, ref, ora = abi.Engine(0), engine_without_hit_mask(), Oracle()
+    se, sr, so = crowded(eng), crowded(ref), crowded(ora)
+    for s in (se, sr, so):
+        s.sph.use_step_frame = s is not so
+        s.start()
+    for f in range(2):
+        state = ora.download_particles()
+        eng.upload_particles(state); ref.upload_particles(state)
+        if f == 0:   # particles are at rest at spawn: the frame's neighbour search sees this crowd
+            x = state[:, 0:3].astype(np.float64)
+            d2 = ((x[:, None, :] - x[None, :, :]) ** 2).sum(-1)
+            assert ((d2 < 0.09).sum(1) - 1).max() > 512      # more hits than mask bits, a fortiori candidates
+        se.frame(); sr.frame(); so.frame()
+        assert eng.read_counter(abi.CTR_BIN_OVERFLOW) == 0
+        assert_neighbors_equal(eng, ora, 4096, f"frame {f}: ")
+        pe = eng.download_particles()
+        assert np.array_equal(pe.view(np.uint32), ref.download_particles().view(np.uint32)), f"frame {f}"
+        assert_fields_close(pe, ora.download_particles(), 1e-5, f"frame {f}: ")
+    eng.destroy(); ref.destroy(); ora.destroy()
+
+
+def test_force_dispatch_without_a_fresh_mask():
+    """Kernel-granular callers may dispatch CS_ForceXSPH after something moved the particles
+    since the last CS_DensityPressure: the library must not trust the stale mask."""
+    from oracle.ora import Oracle
+    eng, ora = abi.Engine(0), Oracle()
+    se, so = scenes.config1(eng, n=4096), scenes.config1(ora, n=4096)
+    se.start(); so.start()
+    se.frame(); so.frame()
+    eng.upload_particles(ora.download_particles())
+    for e, s in ((eng, se), (ora, so)):
+        n, cells = e.n, s.sph.gridResolutionX * s.sph.gridResolutionY * s.sph.gridResolutionZ
+        e.dispatch(abi.K_CLEAR_GRID, cells)
+        e.dispatch(abi.K_BUILD_GRID, n)
+        e.dispatch(abi.K_DENSITY_PRESSURE, n)
+        e.dispatch(abi.K_VV_HALF_STEP, n)           # positions move: mask is stale now
+        e.dispatch(abi.K_FORCE_XSPH, n)
+    assert_fields_close(eng.download_particles(), ora.download_particles(), 1e-5, "stale mask: ")
+    eng.destroy(); ora.destroy()
