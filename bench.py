@@ -143,9 +143,9 @@ def main():
                                f"grid {sc.sph.gridResolutionX}x{sc.sph.gridResolutionY}x{sc.sph.gridResolutionZ}",
                    "particles": n, "sub_steps": sub, "parallelism": "1 GPU",
                    "bin_overflow_cells": overflow},
-        "roofline": {"bound": "hbm", "kernel": "k_force_xsph_rows (CS_ForceXSPH)", "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": "k_force_xsph_hits (CS_ForceXSPH)", "achieved": achieved,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": measured_traffic("k_force_xsph_rows", wl, n),
+                     "traffic": measured_traffic("k_force_xsph_hits", wl, n),
                      "alg_bytes_per_particle": FORCE_BYTES_PER_PARTICLE, "avg_launch_ms": tm["force_ms"],
                      "density_kernel": {"achieved": dens_gbps, "frac": dens_gbps / HBM_PEAK_GBPS,
                                         "alg_bytes_per_particle": DENSITY_BYTES_PER_PARTICLE,

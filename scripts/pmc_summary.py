@@ -8,7 +8,7 @@ by = defaultdict(lambda: defaultdict(list))
 for r in rows:
     by[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in sorted(by.items()):
-    if not any(x in k for x in ("force", "density", "permute", "scatter", "half_step")):
+    if not any(x in k for x in ("force", "density", "permute", "hash_count", "place", "rank", "cum_", "full_bound")):
         continue
     print(k)
     for c, v in sorted(d.items()):

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
                                                                   float2* __restrict__ rhoP,
                                                                   const int* __restrict__ cellCum,
                                                                   const int* __restrict__ counters,
-                                                                  uint32_t* __restrict__ hitMask) {
+                                                                  uint32_t* __restrict__ hitMask, int maskStride) {
     const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
     const int nRanges = capped ? 27 : 9;
     const int s = xcd_tile(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
@@ -142,8 +142,11 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
     // Hit mask for the force kernel (see k_force_xsph_hits): one bit per candidate in visiting
     // order, rows padded to groups of four, kMaskWords words per particle; particles with more
     // candidate groups than fit simply stop recording (the force kernel recomputes the group
-    // count from the same ranges and falls back to scanning).
-    uint32_t* const mrow = (hitMask && !capped) ? hitMask + (size_t)s * kMaskWords : nullptr;
+    // count from the same ranges and falls back to scanning).  Words are staged in LDS and written
+    // out once at the end, 16 bytes at a time: word-by-word global stores left every particle's
+    // line half-written in L2 for the whole kernel and cost 150 B of HBM writes per particle.
+    __shared__ uint32_t maskStage[kMaskWords][kBlock];
+    const bool recording = hitMask && !capped;
     uint32_t word = 0;
     int sh = 0, wi = 0;
     // Keep gathers in flight: the next row's range is fetched while this row is walked, and
@@ -184,11 +187,11 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
             density += k2 ? t2 : 0.0f;
             density += k3 ? t3 : 0.0f;
             const uint32_t h0 = k0, h1 = k1, h2 = k2, h3 = k3;
-            if (mrow) {
+            if (recording) {
                 word |= (h0 | (h1 << 1) | (h2 << 2) | (h3 << 3)) << sh;
                 sh += 4;
                 if (sh == 32) {
-                    if (wi < kMaskWords) mrow[wi] = word;
+                    if (wi < kMaskWords) maskStage[wi][threadIdx.x] = word;
                     wi++;
                     word = 0;
                     sh = 0;
@@ -197,7 +200,21 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
         }
         r = nxt;
     }
-    if (mrow && sh != 0 && wi < kMaskWords) mrow[wi] = word;
+    if (recording) {
+        if (sh != 0 && wi < kMaskWords) maskStage[wi][threadIdx.x] = word;
+        const int nWords = min(wi + (sh != 0 ? 1 : 0), kMaskWords);
+        // the first kMaskWords/2 words of a particle live in one array, the rest (crowded particles
+        // only) in a second one, so the common case touches 32 bytes per particle
+        uint4* const lo = (uint4*)(hitMask + (size_t)s * (kMaskWords / 2));
+        uint4* const hi = (uint4*)(hitMask + ((size_t)maskStride + s) * (kMaskWords / 2));
+#pragma unroll
+        for (int q = 0; q < kMaskWords / 4; q++)
+            if (q * 4 < nWords) {
+                const uint4 w4 = make_uint4(maskStage[q * 4][threadIdx.x], maskStage[q * 4 + 1][threadIdx.x],
+                                            maskStage[q * 4 + 2][threadIdx.x], maskStage[q * 4 + 3][threadIdx.x]);
+                if (q < kMaskWords / 8) lo[q] = w4; else hi[q - kMaskWords / 8] = w4;
+            }
+    }
     const float r0 = rho0[s];
     density = fmaxf(density, r0);                                          // compute:186
     const float localB = r0 * (P.soundSpeed * P.soundSpeed) / P.gamma;     // compute:189
@@ -396,7 +413,8 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
                                                             float4* __restrict__ acc, float4* __restrict__ velOut,
                                                             const int* __restrict__ cellCum,
                                                             const int* __restrict__ counters,
-                                                            const uint32_t* __restrict__ hitMask, int zeroDeadAcc) {
+                                                            const uint32_t* __restrict__ hitMask, int maskStride,
+                                                            int zeroDeadAcc) {
     static_assert(kHitQueue >= 18, "row table shares the FIFO's LDS");
     __shared__ int lds[kHitQueue][kBlock];
     const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
@@ -422,18 +440,19 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
     if (capped || __any(totalNib > kMaskWords * 8)) {
         force_scan(P, A, me, c, capped, posM, velIn, rhoP, cellCum, lds);
     } else {
-        const uint32_t* __restrict__ mrow = hitMask + (size_t)me.sl * kMaskWords;
+        const uint32_t* __restrict__ mlo = hitMask + (size_t)me.sl * (kMaskWords / 2);
+        const uint32_t* __restrict__ mhi = hitMask + ((size_t)maskStride + me.sl) * (kMaskWords / 2) - kMaskWords / 2;
         const int nWords = (totalNib + 7) >> 3;          // 0 for dead lanes
         int wi = 0;
         uint32_t w = 0;
-        uint32_t wnext = nWords > 0 ? mrow[0] : 0u;
+        uint32_t wnext = nWords > 0 ? mlo[0] : 0u;
         int t = 0, rowA = lds[0][tid], nibStart = 0, nibEnd = lds[9][tid];
         const int nLast = P.n - 1;
         auto pop = [&](int& j) -> bool {
             while (w == 0 && wi < nWords) {
                 w = wnext;
                 wi++;
-                wnext = (wi < nWords) ? mrow[wi] : 0u;
+                wnext = (wi < nWords) ? (wi < kMaskWords / 2 ? mlo[wi] : mhi[wi]) : 0u;
             }
             if (w == 0) { j = me.sl; return false; }
             const int B = ((wi - 1) << 5) + __builtin_ctz(w);
