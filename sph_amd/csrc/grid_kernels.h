@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kBlock) void k_hash_count(DevParams P, const float4
         x = min(max(x, 0), P.rx - 1);                    // memory safety only: a slab never holds such a particle
         int y = min(max(c.y, 0), P.ry - 1);
         int z = min(max(c.z, 0), P.rz - 1);
-        key = (uint32_t)(x + y * P.rx + z * P.rx * P.ry);
+        key = (uint32_t)(x + P.rx * row_index(P.ryT, y, z));
         keys[s] = key;
     }
     // Wave-aggregated: consecutive lanes with the same cell (the usual case -- the particles are
@@ -220,12 +220,19 @@ __global__ __launch_bounds__(kBlock) void k_permute_half(int n, float dt, const 
     dst.rho0[k] = src.rho0[s];
 }
 
-// cell_of_particle export: keys are per slot, the caller wants them per id
-__global__ __launch_bounds__(kBlock) void k_scatter_by_id(int n, const uint32_t* __restrict__ in,
+// cell_of_particle export: keys are per slot and in the tiled memory order; the caller wants the
+// reference's cell index (compute:127) per id
+__global__ __launch_bounds__(kBlock) void k_scatter_by_id(DevParams P, const uint32_t* __restrict__ keys,
                                                           const uint32_t* __restrict__ origId,
                                                           uint32_t* __restrict__ out) {
     int s = blockIdx.x * kBlock + threadIdx.x;
-    if (s < n) out[origId[s]] = in[s];
+    if (s >= P.n) return;
+    const uint32_t key = keys[s];
+    const int x = (int)(key % (uint32_t)P.rx), row = (int)(key / (uint32_t)P.rx);
+    const int tile = row >> (kTileYLog + kTileZLog), in = row & (kTileY * kTileZ - 1);
+    const int y = ((tile % P.ryT) << kTileYLog) + (in & (kTileY - 1));
+    const int z = ((tile / P.ryT) << kTileZLog) + (in >> kTileYLog);
+    out[origId[s]] = (uint32_t)(x + y * P.rx + z * P.rx * P.ry);
 }
 
 }  // namespace sph

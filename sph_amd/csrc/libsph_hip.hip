@@ -5,6 +5,7 @@
 // here over HIP.  No CPU fallback exists: without a gfx950 device sph_create fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -49,7 +50,8 @@ struct sph_ctx {
 
     // grid
     int rx = 0, ry = 0, rz = 0, cap = 0;
-    long long cells = 0;
+    long long cells = 0;              // rx * ry * rz, the reference's cell count
+    long long tableCells = 0;         // entries of the tiled cell table (rows padded to whole tiles)
     long long cellCapacity = 0;
     int* cumBase = nullptr;           // allocation behind the cumulative cell table
     int* cumT = nullptr;              // T[c] = #particles with cell <= c (16-byte aligned, T[-1] = 0)
@@ -146,7 +148,7 @@ void freeParticles(sph_ctx* c) {
 void freeGrid(sph_ctx* c) {
     devFree(c->cumBase); devFree(c->cumBlocks);
     c->cumT = c->cellCum = nullptr;
-    c->cellCapacity = 0; c->cells = 0;
+    c->cellCapacity = 0; c->cells = 0; c->tableCells = 0;
 }
 
 int ensurePinned(sph_ctx* c, size_t bytes) {
@@ -178,6 +180,7 @@ void deriveParams(sph_ctx* c) {
     d.rx = c->slab ? c->rx : q.gridResolutionX;
     d.ry = q.gridResolutionY; d.rz = q.gridResolutionZ;
     d.rxg = q.gridResolutionX;
+    d.ryT = tiles_along(d.ry, kTileYLog);
     d.xoff = c->slab ? c->xOffset : 0;
     d.ownLo = c->slab ? c->ownLoG - c->xOffset : 0;
     d.ownHi = c->slab ? c->ownHiG - c->xOffset : d.rx;
@@ -264,7 +267,7 @@ StateSet curSet(sph_ctx* c) {
 // CS_ClearGrid (compute:104-111): a bin is a [start,end) range here, so clearing = zero ranges.
 int clearGrid(sph_ctx* c) {
     // T[-1 .. cells padded to int4): zero = "no particle in any cell"
-    const size_t padded = ((size_t)c->cells + 3) / 4 * 4;
+    const size_t padded = ((size_t)c->tableCells + 3) / 4 * 4;
     HIP_TRY(c, hipMemsetAsync(c->cumBase, 0, sizeof(int) * (padded + 4), c->stream));
     c->gridValid = false;
     c->maskValid = false;
@@ -286,8 +289,8 @@ int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
                        c->cumT, c->counters);
     CHECK_LAUNCH(c);
     {   // counts -> cumulative cell table
-        const long long cells4 = (c->cells + 3) / 4;
-        const int cb = (int)((c->cells + kScanTile - 1) / kScanTile);
+        const long long cells4 = (c->tableCells + 3) / 4;
+        const int cb = (int)((c->tableCells + kScanTile - 1) / kScanTile);
         hipLaunchKernelGGL(k_cum_block_sum, dim3(cb), dim3(kBlock), 0, c->stream, (const int4*)c->cumT, cells4,
                            c->cumBlocks);
         hipLaunchKernelGGL(k_cum_scan_blocks, dim3(1), dim3(kBlock), 0, c->stream, c->cumBlocks, cb);
@@ -513,22 +516,24 @@ int sph_resize_grid(sph_ctx* c, int rx, int ry, int rz, int max_per_cell) {
     if (rx <= 0 || ry <= 0 || rz <= 0 || max_per_cell <= 0)
         return fail(c, SPH_E_INVALID, "bad grid %d x %d x %d cap %d", rx, ry, rz, max_per_cell);
     const long long cells = (long long)rx * ry * rz;
-    if (cells > 0x7FFFFFFFll) return fail(c, SPH_E_INVALID, "grid has %lld cells (> 2^31-1)", cells);
+    // rows are stored in tiles of kTileY x kTileZ (sph_common.h): the table covers whole tiles
+    const long long table = (long long)rx * (tiles_along(ry, kTileYLog) * kTileY) * (tiles_along(rz, kTileZLog) * kTileZ);
+    if (table > 0x7FFFFFF0ll) return fail(c, SPH_E_INVALID, "grid has %lld cells (table of %lld > 2^31)", cells, table);
     HIP_TRY(c, hipSetDevice(c->device));
-    if (cells > c->cellCapacity) {
+    if (table > c->cellCapacity) {
         // grow-only, with headroom: a rocking boundary cube changes the AABB every frame
         // (SPH.cs:176-185 -> 339-345 reallocates each time; here that is a no-op almost always)
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         freeGrid(c);
-        long long want = cells + cells / 4;
-        if (want > 0x7FFFFFFFll) want = 0x7FFFFFFFll;
+        long long want = table + table / 4;
+        if (want > 0x7FFFFFF0ll) want = 0x7FFFFFF0ll;
         int rc = devAlloc(c, &c->cumBase, (size_t)want + 16);
         if (!rc) { c->cumT = c->cumBase + 4; c->cellCum = c->cumT - 1; }
         if (!rc) rc = devAlloc(c, &c->cumBlocks, (size_t)((want + kScanTile - 1) / kScanTile));
         if (rc) { freeGrid(c); return rc; }
         c->cellCapacity = want;
     }
-    c->rx = rx; c->ry = ry; c->rz = rz; c->cap = max_per_cell; c->cells = cells;
+    c->rx = rx; c->ry = ry; c->rz = rz; c->cap = max_per_cell; c->cells = cells; c->tableCells = table;
     c->gridValid = false; c->maskValid = false;   // fresh GridCounts/GridIndices buffers (SPH.cs:344-345)
     return SPH_OK;
 }
@@ -679,18 +684,40 @@ int sph_download_grid(sph_ctx* c, int32_t* cell_start, int32_t* cell_end, int32_
     if (!c->gridValid) return fail(c, SPH_E_STATE, "grid not built");
     if (c->slab && cell_of_particle) return fail(c, SPH_E_STATE, "cell_of_particle is indexed by id: not available in slab mode");
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t cb = sizeof(int) * (size_t)c->cells, nb = sizeof(int) * (size_t)c->n;
-    if (cell_start) HIP_TRY(c, hipMemcpyAsync(cell_start, c->cellCum, cb, hipMemcpyDeviceToHost, c->stream));
-    if (cell_end) HIP_TRY(c, hipMemcpyAsync(cell_end, c->cellCum + 1, cb, hipMemcpyDeviceToHost, c->stream));
-    if (sorted_ids)
-        HIP_TRY(c, hipMemcpyAsync(sorted_ids, c->set[c->cur].origId, nb, hipMemcpyDeviceToHost, c->stream));
+    // Parity export in the REFERENCE's cell order (compute:127): bins are stored in row tiles on the
+    // device, so the table and the id sequence are re-linearised here on the host (export only).
+    const size_t nb = sizeof(int) * (size_t)c->n;
+    deriveParams(c);
+    c->dp.n = c->n;
+    std::vector<int> cum, ids;
+    if (cell_start || cell_end || sorted_ids) {
+        cum.resize((size_t)c->tableCells + 1);
+        ids.resize((size_t)c->n);
+        HIP_TRY(c, hipMemcpyAsync(cum.data(), c->cellCum, sizeof(int) * cum.size(), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(ids.data(), c->set[c->cur].origId, nb, hipMemcpyDeviceToHost, c->stream));
+    }
     if (cell_of_particle) {
-        hipLaunchKernelGGL(k_scatter_by_id, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->n, c->sortedKeys,
+        hipLaunchKernelGGL(k_scatter_by_id, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->dp, c->sortedKeys,
                            c->set[c->cur].origId, c->sid);
         CHECK_LAUNCH(c);
         HIP_TRY(c, hipMemcpyAsync(cell_of_particle, c->sid, nb, hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!cum.empty()) {
+        int run = 0;
+        size_t cell = 0;
+        for (int z = 0; z < c->rz; z++)
+            for (int y = 0; y < c->ry; y++) {
+                const size_t base = (size_t)c->rx * row_index(c->dp.ryT, y, z);
+                for (int x = 0; x < c->rx; x++, cell++) {
+                    const int a = cum[base + x], e = cum[base + x + 1];
+                    if (cell_start) cell_start[cell] = run;
+                    if (sorted_ids) std::copy(ids.begin() + a, ids.begin() + e, sorted_ids + run);
+                    run += e - a;
+                    if (cell_end) cell_end[cell] = run;
+                }
+            }
+    }
     return SPH_OK;
 }
 
@@ -711,7 +738,7 @@ int sph_download_neighbors(sph_ctx* c, int32_t* counts, int32_t* lists, int max_
     }
     StateSet s = curSet(c);
     hipLaunchKernelGGL(k_export_neighbors, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.origId,
-                       c->cellCum, c->cellCum + 1, c->cellCum, c->counters, dCounts, dLists, max_neighbors);
+                       c->cellCum, c->counters, dCounts, dLists, max_neighbors);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(counts, dCounts, sizeof(int) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess && dLists) e = hipMemcpyAsync(lists, dLists, lb, hipMemcpyDeviceToHost, c->stream);

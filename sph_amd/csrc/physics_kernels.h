@@ -16,40 +16,6 @@ __device__ __forceinline__ float dist2_exact(float rx, float ry, float rz) {
     return (a + b) + c;
 }
 
-// Calls f(j) for every candidate slot j of the particle in slot `self` at position (px,py,pz),
-// in the reference's visiting order: z, y, x cells around the UNCLAMPED own cell (rule O7),
-// then ascending id inside a cell, at most `cap` entries per cell (rule O2); skips j == self
-// (compute:158-173 / 229-244).
-template <class F>
-__device__ __forceinline__ void for_each_candidate(const DevParams& P, const int* __restrict__ cellStart,
-                                                   const int* __restrict__ cellEnd, int self, float px, float py,
-                                                   float pz, F&& f) {
-    int3 c = cell_unclamped(P, px, py, pz);
-    // cells further than 1 outside the grid have no in-range neighbour cell; clamping them to
-    // [-2, r+1] keeps that and avoids signed overflow on saturated coordinates
-    c.x = min(max(c.x, -2), P.rxg + 1);
-    c.y = min(max(c.y, -2), P.ry + 1);
-    c.z = min(max(c.z, -2), P.rz + 1);
-    for (int z = c.z - 1; z <= c.z + 1; z++) {
-        if (z < 0 || z >= P.rz) continue;
-        for (int y = c.y - 1; y <= c.y + 1; y++) {
-            if (y < 0 || y >= P.ry) continue;
-            for (int xg = c.x - 1; xg <= c.x + 1; xg++) {
-                if (xg < 0 || xg >= P.rxg) continue;
-                const int x = xg - P.xoff;               // local plane; outside only for ghost targets
-                if (x < 0 || x >= P.rx) continue;
-                const int ci = x + y * P.rx + z * P.rx * P.ry;
-                const int a = cellStart[ci];
-                const int e = min(cellEnd[ci], a + P.cap);
-                for (int j = a; j < e; j++) {
-                    if (j == self) continue;
-                    f(j);
-                }
-            }
-        }
-    }
-}
-
 // CS_Clear (compute:87-98)
 __global__ __launch_bounds__(kBlock) void k_clear(int n, float4* __restrict__ acc, float2* __restrict__ rhoP,
                                                   const float* __restrict__ rho0) {
@@ -99,7 +65,7 @@ __device__ __forceinline__ RowRange row_range(const DevParams& P, const int* __r
     const int xlo = max(max(c.x - 1, 0) - P.xoff, 0), xhi = min(min(c.x + 1, P.rxg - 1) - P.xoff, P.rx - 1);
     RowRange r{0, 0};
     if (live && y >= 0 && y < P.ry && z >= 0 && z < P.rz && xlo <= xhi) {
-        const int base = y * P.rx + z * P.rx * P.ry;
+        const int base = P.rx * row_index(P.ryT, y, z);
         r.a = cellCum[base + xlo];
         r.e = cellCum[base + xhi + 1];
     }
@@ -117,7 +83,7 @@ __device__ __forceinline__ RowRange range_at(const DevParams& P, const int* __re
     const int xg = c.x + (t % 3 - 1), y = c.y + ((t / 3) % 3 - 1), z = c.z + (t / 9 - 1);
     const int x = xg - P.xoff;
     if (live && t < 27 && xg >= 0 && xg < P.rxg && x >= 0 && x < P.rx && y >= 0 && y < P.ry && z >= 0 && z < P.rz) {
-        const int ci = x + y * P.rx + z * P.rx * P.ry;
+        const int ci = x + P.rx * row_index(P.ryT, y, z);
         r.a = cellCum[ci];
         r.e = min(cellCum[ci + 1], r.a + P.cap);
     }
@@ -724,8 +690,6 @@ __global__ __launch_bounds__(kBlock) void k_apply_phase_table(int n, StateSet st
 // same way the production kernels walk it (row ranges when no bin overflowed, capped cells otherwise).
 __global__ __launch_bounds__(kBlock) void k_export_neighbors(DevParams P, const float4* __restrict__ posM,
                                                              const uint32_t* __restrict__ origId,
-                                                             const int* __restrict__ cellStart,
-                                                             const int* __restrict__ cellEnd,
                                                              const int* __restrict__ cellCum,
                                                              const int* __restrict__ counters,
                                                              int* __restrict__ counts, int* __restrict__ lists,
@@ -734,25 +698,20 @@ __global__ __launch_bounds__(kBlock) void k_export_neighbors(DevParams P, const 
     if (s >= P.n) return;
     const float4 p = posM[s];
     const uint32_t id = origId[s];
+    const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;
+    const int3 c = search_cell(P, p.x, p.y, p.z);
     int cnt = 0;
-    auto visit = [&](int j) {
-        const float4 q = posM[j];
-        const float rSq = dist2_exact(p.x - q.x, p.y - q.y, p.z - q.z);
-        if (rSq < P.h2) {
-            if (cnt < maxNeighbors && lists) lists[(size_t)id * maxNeighbors + cnt] = (int)origId[j];
-            cnt++;
-        }
-    };
-    if (counters[SPH_CTR_BIN_OVERFLOW] == 0) {
-        const int3 c = search_cell(P, p.x, p.y, p.z);
-        for (int dz = -1; dz <= 1; dz++)
-            for (int dy = -1; dy <= 1; dy++) {
-                const RowRange r = row_range(P, cellCum, c, dy, dz, true);
-                for (int j = r.a; j < r.e; j++)
-                    if (j != s) visit(j);
+    for (int t = 0; t < (capped ? 27 : 9); t++) {
+        const RowRange r = range_at(P, cellCum, c, t, capped, true);
+        for (int j = r.a; j < r.e; j++) {
+            if (j == s) continue;
+            const float4 q = posM[j];
+            const float rSq = dist2_exact(p.x - q.x, p.y - q.y, p.z - q.z);
+            if (rSq < P.h2) {
+                if (cnt < maxNeighbors && lists) lists[(size_t)id * maxNeighbors + cnt] = (int)origId[j];
+                cnt++;
             }
-    } else {
-        for_each_candidate(P, cellStart, cellEnd, s, p.x, p.y, p.z, visit);
+        }
     }
     counts[id] = cnt;
 }

@@ -29,6 +29,7 @@ struct DevParams {
     // slab decomposition: the local grid is planes [xoff, xoff + rx) of a global grid rxg wide;
     // planes [ownLo, ownHi) (local coordinates) are owned, the rest are ghost planes
     int   rxg, xoff, ownLo, ownHi;
+    int   ryT;               // number of row tiles along y (see row_index)
     float cellSize;
     float minBound[3];
     float M[12];      // rows 0..2 of _BoundaryMatrix    (row 3 is never read: compute:351, 396 take .xyz)
@@ -37,6 +38,24 @@ struct DevParams {
     // derived once on the host in fp32 (ORACLE rule O4)
     float h2, poly6, spikyGradFactor, viscLapFactor, lapColFactor;
 };
+
+// ---- memory order of the cells ("row tiles") --------------------------------------------------------
+// The reference linearises cells as x + rx*(y + ry*z) (compute:127).  Keeping that order in memory
+// puts the rows z-1 / z+1 of a particle's 27-cell neighbourhood a whole z-plane away (tens of MB at
+// 8 M particles): fine while everything sits in the 256 MB Infinity Cache, 2-3x slower per particle
+// once it does not.  Here a (y, z) row keeps its x-contiguity (the neighbour search reads the three
+// x-cells of a row as ONE slot range), but the rows are laid out in tiles of kTileY x kTileZ rows:
+//   key = x + rx * row_index(y, z),  row_index = tile(y>>a, z>>b) * (kTileY*kTileZ) + (z&mz)*kTileY + (y&my)
+// so that eight of the nine rows a particle reads are (mostly) within a few hundred KB of its own.
+// Only the layout changes: bins, visiting order and every exported quantity are the reference's.
+constexpr int kTileYLog = 3, kTileZLog = 3;
+constexpr int kTileY = 1 << kTileYLog, kTileZ = 1 << kTileZLog;
+
+__host__ __device__ __forceinline__ int row_index(int ryT, int y, int z) {
+    return (((z >> kTileZLog) * ryT + (y >> kTileYLog)) << (kTileYLog + kTileZLog)) +
+           ((z & (kTileZ - 1)) << kTileYLog) + (y & (kTileY - 1));
+}
+__host__ __device__ __forceinline__ int tiles_along(int r, int log) { return (r + (1 << log) - 1) >> log; }
 
 // SoA particle state, one "set".  Everything is indexed by SLOT (position in the
 // (cell, id)-sorted order of the last grid build; slot == id right after an upload).
