@@ -389,7 +389,7 @@ def bench_main(args, rank, local_rank, world):
                        "particles": n_total, "sub_steps": sub, "parallelism": f"slab{world}",
                        "halo_violations": viol, "bin_overflow_cells": overflow,
                        "exchange_ms_per_step_rank0": se.exchange_s / args.steps * 1e3},
-            "roofline": {"bound": "hbm", "kernel": "k_force_xsph_rows (CS_ForceXSPH), slowest rank", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "k_force_xsph_hits (CS_ForceXSPH), slowest rank", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                          "avg_launch_ms": force_ms},
             "stage_ms_rank0": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
