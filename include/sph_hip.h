@@ -114,11 +114,13 @@ typedef struct sph_ctx sph_ctx;
 /* Per-stage device time in milliseconds (hipEvents on the ctx's stream), AVERAGED over the
  * sph_step_frame calls since the previous sph_get_timings call (which resets the average).
  * With subSteps > 1 the sub-step stages are those of the last sub-step.  Every recorded event costs a
- * few microseconds of stream time, so by default (SPH_HIP_TIMING=1) only five are recorded per frame:
- * build_grid_ms then includes the half step and full_step_ms is the fused tail (full step + boundary +
- * damping); SPH_HIP_TIMING=2 records every stage boundary, SPH_HIP_TIMING=0 none. */
+ * few microseconds of stream time, so by default (SPH_HIP_TIMING=1) only five are recorded per frame,
+ * and only on every 4th frame (starting with the first frame after sph_get_timings): build_grid_ms then
+ * includes the half step and full_step_ms is the fused tail (full step + boundary + damping);
+ * SPH_HIP_TIMING=2 records every stage boundary of every frame, SPH_HIP_TIMING=0 none.  `frames` is
+ * the number of frames that were timed. */
 typedef struct sph_timings {
-    float build_grid_ms;   /* hash + radix sort + ranges + reorder                */
+    float build_grid_ms;   /* hash + counting sort by cell + reorder             */
     float half_step_ms;
     float density_ms;
     float force_ms;

@@ -69,6 +69,19 @@ __global__ __launch_bounds__(kBlock) void k_hash_count(DevParams P, const float4
     if (m && lane == 0) atomicAdd(&counters[SPH_CTR_OUT_OF_GRID], __popcll(m));
 }
 
+// Zeroes the cumulative table (int4 at a time) and, when a grid build follows, the per-build
+// counters (bin overflow, out of grid, max plane shift) -- one launch instead of two fills.
+__global__ __launch_bounds__(kBlock) void k_clear_table(int4* __restrict__ T4, long long n4, int* __restrict__ counters) {
+    const long long base = (long long)blockIdx.x * (kBlock * 4) + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const long long i = base + (long long)r * kBlock;
+        if (i < n4) T4[i] = make_int4(0, 0, 0, 0);
+    }
+    if (counters && blockIdx.x == 0 && threadIdx.x >= SPH_CTR_BIN_OVERFLOW && threadIdx.x < SPH_CTR_COUNT)
+        counters[threadIdx.x] = 0;
+}
+
 constexpr int kScanVec = 4;                              // int4 per thread per round
 constexpr int kScanRounds = 4;
 constexpr int kScanTile = kBlock * kScanVec * kScanRounds;   // 4096 cells per block
@@ -104,34 +117,21 @@ __global__ __launch_bounds__(kBlock) void k_cum_block_sum(const int4* __restrict
     if (threadIdx.x == 0) blockSum[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
-// exclusive prefix sum over the block sums, one workgroup
-__global__ __launch_bounds__(kBlock) void k_cum_scan_blocks(int* __restrict__ blockSum, int numBlocks) {
-    __shared__ int ws[4];
-    __shared__ int carry;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < numBlocks; base += kBlock) {
-        const int i = base + threadIdx.x;
-        const int v = (i < numBlocks) ? blockSum[i] : 0;
-        const int incl = wave_incl_sum(v, lane);
-        if (lane == 63) ws[wave] = incl;
-        __syncthreads();
-        int off = carry;
-        for (int w = 0; w < wave; w++) off += ws[w];
-        if (i < numBlocks) blockSum[i] = off + incl - v;
-        __syncthreads();
-        if (threadIdx.x == kBlock - 1) carry = off + incl;
-        __syncthreads();
-    }
-}
-
-// in-place inclusive prefix sum of one 4096-cell tile, seeded with the tile's exclusive prefix
+// in-place inclusive prefix sum of one 4096-cell tile.  Its seed -- the sum of all earlier tiles -- is
+// reduced here from the per-tile sums (a few hundred to a few thousand ints, L2-resident) instead of
+// by a separate one-workgroup scan kernel.
 __global__ __launch_bounds__(kBlock) void k_cum_write(int4* __restrict__ T4, long long cells4,
-                                                      const int* __restrict__ blockPrefix) {
+                                                      const int* __restrict__ blockSum) {
     __shared__ int ws[4];
+    __shared__ int seed[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int carry = blockPrefix[blockIdx.x];
+    int part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += kBlock) part += blockSum[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (lane == 0) seed[wave] = part;
+    __syncthreads();
+    int carry = (seed[0] + seed[1]) + (seed[2] + seed[3]);
     const long long base = (long long)blockIdx.x * (kBlock * kScanRounds) + threadIdx.x;
 #pragma unroll 1
     for (int r = 0; r < kScanRounds; r++) {

@@ -23,6 +23,7 @@ namespace {
 
 constexpr int kNumEvents = 8;    // stage boundaries of one frame
 constexpr int kTimingRing = 32;  // frames whose events may be outstanding
+constexpr int kTimingStride = 4;  // SPH_HIP_TIMING=1: frames between timed frames (an event costs ~5 us of stream time)
 
 struct DevBuf {
     void* p = nullptr;
@@ -89,7 +90,8 @@ struct sph_ctx {
     bool slotPending[kTimingRing] = {};
     int ringNext = 0;
     double stageSum[kNumEvents] = {};   // ms; [7] = whole frame
-    int timingLevel = 1;                // 0 none, 1 frame + density + force (default), 2 every stage
+    int timingLevel = 1;                // 0 none, 1 frame + density + force on sampled frames (default), 2 every stage
+    int framesSinceHarvest = 0;         // level 1 records events on every kTimingStride-th frame only
     int framesTimed = 0;
 };
 
@@ -264,11 +266,15 @@ StateSet curSet(sph_ctx* c) {
     return s;
 }
 
-// CS_ClearGrid (compute:104-111): a bin is a [start,end) range here, so clearing = zero ranges.
-int clearGrid(sph_ctx* c) {
-    // T[-1 .. cells padded to int4): zero = "no particle in any cell"
-    const size_t padded = ((size_t)c->tableCells + 3) / 4 * 4;
-    HIP_TRY(c, hipMemsetAsync(c->cumBase, 0, sizeof(int) * (padded + 4), c->stream));
+// CS_ClearGrid (compute:104-111): a bin is a range of the cumulative table here, so clearing = zeroing
+// the table.  One launch also resets the per-build counters when a build follows.
+int clearGrid(sph_ctx* c, bool resetBuildCounters = false) {
+    // T[-4 .. cells padded to int4): zero = "no particle in any cell"
+    const size_t padded = ((size_t)c->tableCells + 3) / 4 * 4 + 4;
+    const long long n4 = (long long)(padded / 4);
+    hipLaunchKernelGGL(k_clear_table, dim3((unsigned)((n4 + kBlock * 4 - 1) / (kBlock * 4))), dim3(kBlock), 0, c->stream,
+                       (int4*)c->cumBase, n4, resetBuildCounters ? c->counters : (int*)nullptr);
+    CHECK_LAUNCH(c);
     c->gridValid = false;
     c->maskValid = false;
     return SPH_OK;
@@ -279,9 +285,8 @@ int clearGrid(sph_ctx* c) {
 int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
     const int n = c->n;
     const int nb = blocksFor(n);
-    int rc = clearGrid(c);
+    int rc = clearGrid(c, true);
     if (rc) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->counters + SPH_CTR_BIN_OVERFLOW, 0, 3 * sizeof(int), c->stream));
     StateSet src = curSet(c);
     // keys[0] = cell per old slot, vals[0] = arrival number; keys[1] / vals[1] / sid = key, source slot
     // and id per bucket slot
@@ -293,7 +298,6 @@ int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
         const int cb = (int)((c->tableCells + kScanTile - 1) / kScanTile);
         hipLaunchKernelGGL(k_cum_block_sum, dim3(cb), dim3(kBlock), 0, c->stream, (const int4*)c->cumT, cells4,
                            c->cumBlocks);
-        hipLaunchKernelGGL(k_cum_scan_blocks, dim3(1), dim3(kBlock), 0, c->stream, c->cumBlocks, cb);
         hipLaunchKernelGGL(k_cum_write, dim3(cb), dim3(kBlock), 0, c->stream, (int4*)c->cumT, cells4, c->cumBlocks);
     }
     c->sortedKeys = c->keys[1];
@@ -620,7 +624,9 @@ int sph_step_frame(sph_ctx* c, int sub_steps, float time_step) {
     const int slot = c->ringNext;
     if (c->slotPending[slot] && (rc = harvestSlot(c, slot))) return rc;
     hipEvent_t* ev = c->ev[slot];
-    const int tl = c->timingLevel;
+    // level 1 times every kTimingStride-th frame, starting with the first one after sph_get_timings
+    const int tl = (c->timingLevel == 1 && c->framesSinceHarvest % kTimingStride != 0) ? 0 : c->timingLevel;
+    c->framesSinceHarvest++;
     if (tl >= 1) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
     sph_set_delta_time(c, time_step / (float)sub_steps);                    // SPH.cs:207-208
     // SPH.cs:201 + 204: CS_ClearGrid is the first step of the grid build here; the state reorder at
@@ -758,7 +764,10 @@ int sph_get_timings(sph_ctx* c, sph_timings* out) {
             int rc = harvestSlot(c, r);
             if (rc) return rc;
         }
-    if (c->framesTimed == 0) return fail(c, SPH_E_STATE, "no sph_step_frame has run since the last sph_get_timings");
+    if (c->framesTimed == 0) {
+        c->framesSinceHarvest = 0;
+        return fail(c, SPH_E_STATE, "no timed sph_step_frame has run since the last sph_get_timings");
+    }
     const double inv = 1.0 / c->framesTimed;
     out->build_grid_ms = (float)(c->stageSum[0] * inv);
     out->half_step_ms = (float)(c->stageSum[1] * inv);
@@ -771,6 +780,7 @@ int sph_get_timings(sph_ctx* c, sph_timings* out) {
     out->frames = c->framesTimed;
     for (int k = 0; k < kNumEvents; k++) c->stageSum[k] = 0;
     c->framesTimed = 0;
+    c->framesSinceHarvest = 0;
     return SPH_OK;
 }
 
