@@ -39,6 +39,22 @@ def measured_traffic(kernel, workload, n):
         return None
 
 
+def valu_issue(kernel, workload, n, launch_ms):
+    """Secondary roofline of a neighbour kernel: VALU wave-instructions per launch (SQ_INSTS_VALU from the
+    committed PMC pass of this workload) / live launch time, against the issue rate measured on this
+    chip (scripts/experiments/valu_rate.hip).  These kernels are bound by candidate tests, not by HBM."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+        if t["workload"] != workload or t["particles"] != n:
+            return None
+        insts = t["kernels"][kernel]["SQ_INSTS_VALU"]
+        peak = t["valu_issue_peak"]["wave_insts_per_s_per_simd"] * t["valu_issue_peak"]["simds"] / 1e9
+        ach = insts / (launch_ms * 1e-3) / 1e9
+        return {"wave_insts_per_launch": insts, "achieved": ach, "peak": peak, "unit": "G wave-inst/s", "frac": ach / peak}
+    except Exception:
+        return None
+
+
 def cpu_baseline(scene_builder, start_state, frames_done, budget_s=15.0):
     """Times the OpenMP oracle (kind "port") on the same workload, continuing from the state the
     GPU reached after warm-up, for a bounded number of frames."""
@@ -147,9 +163,12 @@ def main():
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": measured_traffic("k_force_xsph_hits", wl, n),
                      "alg_bytes_per_particle": FORCE_BYTES_PER_PARTICLE, "avg_launch_ms": tm["force_ms"],
+                     "valu_issue": valu_issue("k_force_xsph_hits", wl, n, tm["force_ms"]),
                      "density_kernel": {"achieved": dens_gbps, "frac": dens_gbps / HBM_PEAK_GBPS,
                                         "alg_bytes_per_particle": DENSITY_BYTES_PER_PARTICLE,
-                                        "avg_launch_ms": tm["density_ms"]}},
+                                        "avg_launch_ms": tm["density_ms"],
+                                        "traffic": measured_traffic("k_density_pressure_rows", wl, n),
+                                        "valu_issue": valu_issue("k_density_pressure_rows", wl, n, tm["density_ms"])}},
         "stage_ms": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
     }
     if not args.no_cpu_baseline:
