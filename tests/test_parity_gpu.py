@@ -51,3 +51,14 @@ def test_scene4_obstacle_lockstep():
 
 def test_step_frame_equals_dispatch_sequence():
     lockstep(scenes.unity_scene, 3, which=2, scale_count=0.02, step_frame=True)
+
+
+@pytest.mark.parametrize("step_frame", [False, True])
+def test_two_sub_steps_lockstep(step_frame):
+    """subSteps = 2 (SPH.cs:207-219): the grid is built once, the second sub-step searches it with
+    positions two half-steps old; sph_step_frame folds only the FIRST half step into the reorder."""
+    def builder(e, **kw):
+        sc = scenes.unity_scene(e, which=4, scale_count=0.02)
+        sc.sph.subSteps = 2
+        return sc
+    lockstep(builder, 3, step_frame=step_frame)
