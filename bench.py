@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--particles", type=int, default=0, help="override the particle count (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="", help="config2|config3|config4|config5 (default by --gpus)")
+    ap.add_argument("--workload", default="", help="config2|config3|config4|config5|config5narrow (default: config3)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,6 +112,7 @@ def main():
         "config3": lambda e: scenes.config3(e, n=args.particles or 1048576),
         "config4": lambda e: scenes.config4(e, n=args.particles or 16777216),
         "config5": lambda e: scenes.config5(e, gpus=1, per_gpu=args.particles or 8388608),
+        "config5narrow": lambda e: scenes.config5(e, gpus=1, per_gpu=args.particles or 8388608, block=(20.0, 256.0)),
     }
     builder = builders[wl]
     eng = abi.Engine(local_rank)

@@ -10,7 +10,8 @@ from sph_amd import abi, scenes
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1048576
 eng = abi.Engine(0)
-sc = scenes.config3(eng, n=n)
+wl = sys.argv[3] if len(sys.argv) > 3 else "config3"
+sc = scenes.config3(eng, n=n) if wl == "config3" else scenes.config5(eng, gpus=1, per_gpu=n)
 sc.sph.use_step_frame = True
 sc.start()
 for _ in range(W):

@@ -67,6 +67,7 @@ struct sph_ctx {
     uint32_t* hitMask = nullptr;      // 2 x capacity x kMaskWords/2 words, written by CS_DensityPressure
     bool maskValid = false;           // hitMask matches the current positions and grid
     bool useHitMask = true;           // SPH_HIP_HITMASK=0 turns the hit path off
+    int xcdRunOverride = 0;           // SPH_HIP_XCD_RUN=<n> pins the XCD run length (experiments)
 
     int* counters = nullptr;          // SPH_CTR_COUNT ints on the device
 
@@ -183,6 +184,14 @@ void deriveParams(sph_ctx* c) {
     d.ry = q.gridResolutionY; d.rz = q.gridResolutionZ;
     d.rxg = q.gridResolutionX;
     d.ryT = tiles_along(d.ry, kTileYLog);
+    {   // XCD run length (see xcd_tile): 16 runs per XCD, between 16 and 512 workgroups.  Measured on
+        // config 3 (1 M particles: 32 best) and config 5 (8.4 M: 128-512 best, 16 is 25 % slower).
+        const int nwg = (c->n + kBlock - 1) / kBlock;
+        int run = nwg / 128;
+        if (run < 16) run = 16;
+        if (run > 512) run = 512;
+        d.xcdRun = c->xcdRunOverride > 0 ? c->xcdRunOverride : run;
+    }
     d.xoff = c->slab ? c->xOffset : 0;
     d.ownLo = c->slab ? c->ownLoG - c->xOffset : 0;
     d.ownHi = c->slab ? c->ownHiG - c->xOffset : d.rx;
@@ -401,6 +410,7 @@ int sph_create(sph_ctx** out, int device_id) {
     c->device = device_id;
     if (const char* tl = getenv("SPH_HIP_TIMING")) c->timingLevel = atoi(tl);
     if (const char* hm = getenv("SPH_HIP_HITMASK")) c->useHitMask = atoi(hm) != 0;
+    if (const char* xr = getenv("SPH_HIP_XCD_RUN")) c->xcdRunOverride = atoi(xr);
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return SPH_E_HIP;

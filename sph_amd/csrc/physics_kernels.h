@@ -30,24 +30,24 @@ __global__ __launch_bounds__(kBlock) void k_clear(int n, float4* __restrict__ ac
 // (compute:127), hence adjacent in the sorted order: their bins are ONE slot range, read from the
 // cumulative table with two loads.  Visiting order is unchanged: z, y, then x-1, x, x+1, then id.
 struct RowRange { int a, e; };
+
+
 constexpr int kMaskWords = 16;   // hit-mask words per particle: 128 candidate groups of four
 
-#ifndef SPH_XCD_RUN
-#define SPH_XCD_RUN 16
-#endif
 // XCD-aware workgroup -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs, each with
-// its own 4 MiB L2; consecutive tiles of the (cell, id) order share most of their neighbour rows, so
-// give every XCD one CONTIGUOUS eighth of the tiles instead of every eighth tile: its L2 then holds
-// an eighth of the particle arrays (plus a halo) instead of seeing all of them.  Bijective for any
-// grid size (MI355X guide, T1); affects speed only, never results.
-__device__ __forceinline__ int xcd_tile(int bid, int nwg) {
-    // groups of kXcdRun consecutive tiles stay on one XCD; groups are dealt round-robin so that
-    // regions of different cost per particle (dense / sparse, phase A / phase B) spread evenly
-    constexpr int kXcdRun = SPH_XCD_RUN;
-    const int full = nwg / (8 * kXcdRun) * (8 * kXcdRun);
+// its own 4 MiB L2; consecutive tiles of the slot order share most of their neighbour rows, so runs
+// of `run` CONSECUTIVE tiles are mapped to one XCD instead of every eighth tile (MI355X guide, T1).
+// Runs are dealt round-robin so that regions of different cost per particle (dense / sparse, phase
+// A / phase B) spread evenly; the host picks the run length (DevParams::xcdRun): long enough that an
+// XCD sweeps several whole cell rows and re-uses in its own L2 the rows it fetched for the row
+// before, short enough that every XCD gets many runs.  Bijective for any grid size; affects speed
+// only, never results.
+__device__ __forceinline__ int xcd_tile(int bid, int nwg, int run) {
+    const int span = 8 * run;
+    const int full = nwg / span * span;
     if (bid >= full) return bid;                     // ragged tail: identity
-    const int g = bid / (8 * kXcdRun), w = bid % (8 * kXcdRun);
-    return g * (8 * kXcdRun) + (w & 7) * kXcdRun + (w >> 3);
+    const int g = bid / span, w = bid - g * span;
+    return g * span + (w & 7) * run + (w >> 3);
 }
 
 __device__ __forceinline__ int3 search_cell(const DevParams& P, float px, float py, float pz) {
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
                                                                   uint32_t* __restrict__ hitMask, int maskStride) {
     const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
     const int nRanges = capped ? 27 : 9;
-    const int s = xcd_tile(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+    const int s = xcd_tile(blockIdx.x, gridDim.x, P.xcdRun) * kBlock + threadIdx.x;
     if (s >= P.n) return;
     const float4 p = posM[s];
     const int3 c = search_cell(P, p.x, p.y, p.z);
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_rows(DevParams P, const f
                                                             const int* __restrict__ counters, int zeroDeadAcc) {
     __shared__ int queue[kHitQueue][kBlock];
     const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
-    const int s = xcd_tile(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+    const int s = xcd_tile(blockIdx.x, gridDim.x, P.xcdRun) * kBlock + threadIdx.x;
     const ForceSelf me = force_load_self(P, s, posM, velIn, rhoP);
     ForceAcc A{0.0f, P.gravity * me.densitySelf, 0.0f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // compute:219
     const int3 c = search_cell(P, me.p.x, me.p.y, me.p.z);
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
     static_assert(kHitQueue >= 18, "row table shares the FIFO's LDS");
     __shared__ int lds[kHitQueue][kBlock];
     const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
-    const int s = xcd_tile(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+    const int s = xcd_tile(blockIdx.x, gridDim.x, P.xcdRun) * kBlock + threadIdx.x;
     const ForceSelf me = force_load_self(P, s, posM, velIn, rhoP);
     ForceAcc A{0.0f, P.gravity * me.densitySelf, 0.0f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // compute:219
     const int3 c = search_cell(P, me.p.x, me.p.y, me.p.z);

@@ -30,6 +30,7 @@ struct DevParams {
     // planes [ownLo, ownHi) (local coordinates) are owned, the rest are ghost planes
     int   rxg, xoff, ownLo, ownHi;
     int   ryT;               // number of row tiles along y (see row_index)
+    int   xcdRun;            // consecutive workgroups of a neighbour kernel kept on one XCD (xcd_tile)
     float cellSize;
     float minBound[3];
     float M[12];      // rows 0..2 of _BoundaryMatrix    (row 3 is never read: compute:351, 396 take .xyz)

@@ -116,18 +116,22 @@ def config4(engine, n=16777216, seed=12345) -> Scene:
     return Scene(sph, Time(), [])
 
 
-def config5(engine, gpus=1, per_gpu=8388608, seed=12345) -> Scene:
-    """Config 5: weak scaling, 8,388,608 particles per GPU, G blocks of 80 x 96 x 64 along x."""
+def config5(engine, gpus=1, per_gpu=8388608, seed=12345, block=(80.0, 64.0)) -> Scene:
+    """Config 5: weak scaling, 8,388,608 particles per GPU, G blocks of 80 x 96 x 64 along x.
+    `block` = (x, z) extent of one GPU's block; other shapes of the same volume and spawn density are
+    used by locality experiments only."""
     G = gpus
+    bx, bz = block
     a, b = _split21(per_gpu)
     boxes = []
+    sx, sz = bx - 4.0, 76.0 * 13.0 / (bx - 4.0)          # spawn box footprint of constant area
     for g in range(G):
-        xc = -40.0 * G + 40.0 + 80.0 * g
-        boxes.append(SpawnBox(a, (76, 8, 13), 20, 0.1, 0.2, particleColor=WATER, position=(xc, 48, 16)))
-        boxes.append(SpawnBox(b, (76, 8, 13), 10, 0.1, 0.2, particleColor=OIL, position=(xc, 48, -16)))
-    cube = Transform(position=(0, 48, 0), localScale=(80 * G, 96, 64))
+        xc = -0.5 * bx * G + 0.5 * bx + bx * g
+        boxes.append(SpawnBox(a, (sx, 8, sz), 20, 0.1, 0.2, particleColor=WATER, position=(xc, 48, 0.25 * bz)))
+        boxes.append(SpawnBox(b, (sx, 8, sz), 10, 0.1, 0.2, particleColor=OIL, position=(xc, 48, -0.25 * bz)))
+    cube = Transform(position=(0, 48, 0), localScale=(bx * G, 96, bz))
     f = dict(SCENE_COMMON)
-    f.update(gridResolution=256)
+    f.update(gridResolution=int(round(min(bx * G, 96.0, bz) / 0.25)))      # cell size 0.25 (SPH.cs:329)
     sph = SPH(engine, **f, surfaceTensionCoefficient=0.01, xsphEpsilon=0.2, boundaryCube=cube, obstacleCollider=None,
               spawnBoxes=boxes, seed=seed)
     return Scene(sph, Time(), [])
