@@ -64,7 +64,7 @@ struct sph_ctx {
     uint32_t* perm2 = nullptr;
     uint32_t* sortedKeys = nullptr;   // alias into keys[] after the last build
     bool gridValid = false;
-    uint32_t* hitMask = nullptr;      // 2 x capacity x kMaskWords/2 words, written by CS_DensityPressure
+    uint32_t* hitMask = nullptr;      // kMaskWords words per slot, written by CS_DensityPressure
     bool maskValid = false;           // hitMask matches the current positions and grid
     bool useHitMask = true;           // SPH_HIP_HITMASK=0 turns the hit path off
     int xcdRunOverride = 0;           // SPH_HIP_XCD_RUN=<n> pins the XCD run length (experiments)
@@ -344,8 +344,7 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false)
             return buildGrid(c);
         case SPH_K_DENSITY_PRESSURE:
             hipLaunchKernelGGL(k_density_pressure_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.rho0,
-                               s.rhoP, c->cellCum, c->counters, c->useHitMask ? c->hitMask : (uint32_t*)nullptr,
-                               c->capacity);
+                               s.rhoP, c->cellCum, c->counters, c->useHitMask ? c->hitMask : (uint32_t*)nullptr);
             c->maskValid = c->useHitMask && c->hitMask;
             if (c->slab)
                 hipLaunchKernelGGL(k_slab_plane_shift, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, c->sortedKeys,
@@ -355,7 +354,7 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false)
             float4* velOut = c->set[1 - c->velCur].velV;
             if (c->maskValid)
                 hipLaunchKernelGGL(k_force_xsph_hits, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV,
-                                   s.rhoP, s.acc, velOut, c->cellCum, c->counters, c->hitMask, c->capacity, fused ? 1 : 0);
+                                   s.rhoP, s.acc, velOut, c->cellCum, c->counters, c->hitMask, fused ? 1 : 0);
             else
                 hipLaunchKernelGGL(k_force_xsph_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV,
                                    s.rhoP, s.acc, velOut, c->cellCum, c->counters, fused ? 1 : 0);

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(kBlock) void k_clear(int n, float4* __restrict__ ac
 struct RowRange { int a, e; };
 
 
-constexpr int kMaskWords = 16;   // hit-mask words per particle: 128 candidate groups of four
+constexpr int kMaskWords = 16;   // hit-mask words per particle (one 64-byte line); rows start on word boundaries
 
 // XCD-aware workgroup -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs, each with
 // its own 4 MiB L2; consecutive tiles of the slot order share most of their neighbour rows, so runs
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
                                                                   float2* __restrict__ rhoP,
                                                                   const int* __restrict__ cellCum,
                                                                   const int* __restrict__ counters,
-                                                                  uint32_t* __restrict__ hitMask, int maskStride) {
+                                                                  uint32_t* __restrict__ hitMask) {
     const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
     const int nRanges = capped ? 27 : 9;
     const int s = xcd_tile(blockIdx.x, gridDim.x, P.xcdRun) * kBlock + threadIdx.x;
@@ -105,12 +105,13 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
     const float4 p = posM[s];
     const int3 c = search_cell(P, p.x, p.y, p.z);
     float density = 0.0f;
-    // Hit mask for the force kernel (see k_force_xsph_hits): one bit per candidate in visiting
-    // order, rows padded to groups of four, kMaskWords words per particle; particles with more
-    // candidate groups than fit simply stop recording (the force kernel recomputes the group
-    // count from the same ranges and falls back to scanning).  Words are staged in LDS and written
-    // out once at the end, 16 bytes at a time: word-by-word global stores left every particle's
-    // line half-written in L2 for the whole kernel and cost 150 B of HBM writes per particle.
+    // Hit mask for the force kernel (see k_force_xsph_hits): one bit per candidate slot, every row
+    // starting a fresh 32-bit word (bit b of a row's k-th word = slot row.a + 32 k + b), so that a
+    // set bit decodes to a slot with one add; kMaskWords words per particle.  Particles whose rows
+    // need more words simply stop recording (the force kernel recomputes the word count from the
+    // same ranges and falls back to scanning).  Words are staged in LDS and written out once at
+    // the end, 16 bytes at a time: word-by-word global stores left every particle's line
+    // half-written in L2 for the whole kernel and cost 150 B of HBM writes per particle.
     __shared__ uint32_t maskStage[kMaskWords][kBlock];
     const bool recording = hitMask && !capped;
     uint32_t word = 0;
@@ -164,22 +165,22 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
                 }
             }
         }
+        if (recording && sh != 0) {                      // rows are padded to whole words
+            if (wi < kMaskWords) maskStage[wi][threadIdx.x] = word;
+            wi++;
+            word = 0;
+            sh = 0;
+        }
         r = nxt;
     }
     if (recording) {
-        if (sh != 0 && wi < kMaskWords) maskStage[wi][threadIdx.x] = word;
-        const int nWords = min(wi + (sh != 0 ? 1 : 0), kMaskWords);
-        // the first kMaskWords/2 words of a particle live in one array, the rest (crowded particles
-        // only) in a second one, so the common case touches 32 bytes per particle
-        uint4* const lo = (uint4*)(hitMask + (size_t)s * (kMaskWords / 2));
-        uint4* const hi = (uint4*)(hitMask + ((size_t)maskStride + s) * (kMaskWords / 2));
+        const int nWords = min(wi, kMaskWords);
+        uint4* const row = (uint4*)(hitMask + (size_t)s * kMaskWords);
 #pragma unroll
         for (int q = 0; q < kMaskWords / 4; q++)
-            if (q * 4 < nWords) {
-                const uint4 w4 = make_uint4(maskStage[q * 4][threadIdx.x], maskStage[q * 4 + 1][threadIdx.x],
-                                            maskStage[q * 4 + 2][threadIdx.x], maskStage[q * 4 + 3][threadIdx.x]);
-                if (q < kMaskWords / 8) lo[q] = w4; else hi[q - kMaskWords / 8] = w4;
-            }
+            if (q * 4 < nWords)
+                row[q] = make_uint4(maskStage[q * 4][threadIdx.x], maskStage[q * 4 + 1][threadIdx.x],
+                                    maskStage[q * 4 + 2][threadIdx.x], maskStage[q * 4 + 3][threadIdx.x]);
     }
     const float r0 = rho0[s];
     density = fmaxf(density, r0);                                          // compute:186
@@ -371,66 +372,76 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_rows(DevParams P, const f
 
 // Hit path.  PRECONDITION (kept by the host, libsph_hip.hip `maskValid`): hitMask was written by
 // k_density_pressure_rows on exactly these positions and this grid.  A wave falls back to the scan
-// path if a bin overflowed (27 capped ranges, no mask) or any of its particles has more candidate
-// groups than the mask holds.
+// path if a bin overflowed (27 capped ranges, no mask) or any of its particles needs more mask words
+// than a row holds.
 __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const float4* __restrict__ posM,
                                                             const float4* __restrict__ velIn,
                                                             const float2* __restrict__ rhoP,
                                                             float4* __restrict__ acc, float4* __restrict__ velOut,
                                                             const int* __restrict__ cellCum,
                                                             const int* __restrict__ counters,
-                                                            const uint32_t* __restrict__ hitMask, int maskStride,
-                                                            int zeroDeadAcc) {
-    static_assert(kHitQueue >= 18, "row table shares the FIFO's LDS");
-    __shared__ int lds[kHitQueue][kBlock];
+                                                            const uint32_t* __restrict__ hitMask, int zeroDeadAcc) {
+    // one buffer, two uses: (a) per lane the non-empty mask words and the slot of their bit 0,
+    // (b) the scan path's hit FIFO.  Every thread only touches its own column.
+    static_assert(2 * kMaskWords >= kHitQueue, "the FIFO lives in the word list's LDS");
+    __shared__ int lds[2 * kMaskWords][kBlock];
+    int (*const wordOf)[kBlock] = lds;                   // [kMaskWords]
+    int (*const baseOf)[kBlock] = lds + kMaskWords;      // [kMaskWords]
     const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
     const int s = xcd_tile(blockIdx.x, gridDim.x, P.xcdRun) * kBlock + threadIdx.x;
     const ForceSelf me = force_load_self(P, s, posM, velIn, rhoP);
     ForceAcc A{0.0f, P.gravity * me.densitySelf, 0.0f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // compute:219
     const int3 c = search_cell(P, me.p.x, me.p.y, me.p.z);
     const int tid = threadIdx.x;
-    int totalNib = 0;
+    RowRange rr[9];
+    int nWords = 0;
     if (!capped) {
-        // row table in LDS: rows 0..8 = first slot of the row, rows 9..17 = running count of
-        // candidate groups up to and including the row (the mask's bit layout)
-        RowRange rr[9];
-#pragma unroll
-        for (int t = 0; t < 9; t++) rr[t] = row_range(P, cellCum, c, t % 3 - 1, t / 3 - 1, me.live);
 #pragma unroll
         for (int t = 0; t < 9; t++) {
-            lds[t][tid] = rr[t].a;
-            totalNib += (rr[t].e - rr[t].a + 3) >> 2;
-            lds[9 + t][tid] = totalNib;
+            rr[t] = row_range(P, cellCum, c, t % 3 - 1, t / 3 - 1, me.live);
+            nWords += (rr[t].e - rr[t].a + 31) >> 5;
         }
     }
-    if (capped || __any(totalNib > kMaskWords * 8)) {
+    if (capped || __any(nWords > kMaskWords)) {
         force_scan(P, A, me, c, capped, posM, velIn, rhoP, cellCum, lds);
     } else {
-        const uint32_t* __restrict__ mlo = hitMask + (size_t)me.sl * (kMaskWords / 2);
-        const uint32_t* __restrict__ mhi = hitMask + ((size_t)maskStride + me.sl) * (kMaskWords / 2) - kMaskWords / 2;
-        const int nWords = (totalNib + 7) >> 3;          // 0 for dead lanes
-        int wi = 0;
+        // 1) the particle's mask row -> LDS (16 bytes at a time, only the part in use)
+        const uint4* __restrict__ mrow = (const uint4*)(hitMask + (size_t)me.sl * kMaskWords);
+#pragma unroll
+        for (int q = 0; q < kMaskWords / 4; q++)
+            if (q * 4 < nWords) {
+                const uint4 v = mrow[q];
+                wordOf[q * 4][tid] = (int)v.x; wordOf[q * 4 + 1][tid] = (int)v.y;
+                wordOf[q * 4 + 2][tid] = (int)v.z; wordOf[q * 4 + 3][tid] = (int)v.w;
+            }
+        // 2) keep the non-empty words, each with the slot its bit 0 stands for (in place: the write
+        //    position never overtakes the read position)
+        int cnt = 0, idx = 0;
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int nw = (rr[t].e - rr[t].a + 31) >> 5;
+            for (int k = 0; k < nw; k++, idx++) {
+                const int w = wordOf[idx][tid];
+                if (w != 0) {
+                    wordOf[cnt][tid] = w;
+                    baseOf[cnt][tid] = rr[t].a + (k << 5);
+                    cnt++;
+                }
+            }
+        }
+        // 3) walk the set bits: visiting order, one add per hit to find its slot
+        int li = 0, base = 0;
         uint32_t w = 0;
-        uint32_t wnext = nWords > 0 ? mlo[0] : 0u;
-        int t = 0, rowA = lds[0][tid], nibStart = 0, nibEnd = lds[9][tid];
         const int nLast = P.n - 1;
         auto pop = [&](int& j) -> bool {
-            while (w == 0 && wi < nWords) {
-                w = wnext;
-                wi++;
-                wnext = (wi < nWords) ? (wi < kMaskWords / 2 ? mlo[wi] : mhi[wi]) : 0u;
+            if (w == 0 && li < cnt) {
+                w = (uint32_t)wordOf[li][tid];
+                base = baseOf[li][tid];
+                li++;
             }
             if (w == 0) { j = me.sl; return false; }
-            const int B = ((wi - 1) << 5) + __builtin_ctz(w);
+            j = min(base + __builtin_ctz(w), nLast);     // the min only guards against a stale mask
             w &= w - 1;
-            const int nb = B >> 2;
-            while (nb >= nibEnd && t < 8) {
-                t++;
-                rowA = lds[t][tid];
-                nibStart = nibEnd;
-                nibEnd = lds[9 + t][tid];
-            }
-            j = min(rowA + ((nb - nibStart) << 2) + (B & 3), nLast);
             return true;
         };
         // Software-pipelined, two pairs per stage: the six gathers of the next two hits are issued
