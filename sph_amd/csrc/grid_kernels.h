@@ -28,7 +28,7 @@ __device__ __forceinline__ int3 cell_unclamped(const DevParams& P, float x, floa
 //                  arrival number inside the cell (order of arrival is arbitrary);
 //   k_cum_*      : in-place inclusive prefix sum over the cells (int4, 4096 cells per workgroup);
 //   k_place      : bucket slot = cellCum[cell] + arrival;
-//   k_rank_in_cell (below) then orders every cell by particle id, which removes the arbitrariness:
+//   k_rank_move (below) then orders every cell by particle id, which removes the arbitrariness:
 //                  the result is the unique (cell, id) order whatever order the atomics ran in.
 // Particles are still in last frame's (cell, id) order when this runs, so consecutive lanes hit the
 // same or neighbouring table entries; runs of equal cells inside a wave share one atomic.
@@ -165,59 +165,44 @@ __global__ __launch_bounds__(kBlock) void k_place(int n, const uint32_t* __restr
     sid[t] = origId[s];
 }
 
-// Within each cell, order by particle id (bucket order is the atomics' arrival order).
-// rank = #ids in the cell smaller than mine.
-// Also counts cells whose population exceeds the reference's bin capacity (compute:131).
-__global__ __launch_bounds__(kBlock) void k_rank_in_cell(const uint32_t* __restrict__ sortedKeys,
-                                                         const uint32_t* __restrict__ perm,
-                                                         const uint32_t* __restrict__ sid, int n, int cap,
-                                                         const int* __restrict__ cellStart,
-                                                         const int* __restrict__ cellEnd,
-                                                         uint32_t* __restrict__ perm2, uint32_t* __restrict__ newOrigId,
-                                                         int* __restrict__ counters) {
+// Within each cell, order by particle id (bucket order is the atomics' arrival order): rank = #ids in
+// the cell smaller than mine; cells hold ~1-15 particles.  Also counts cells whose population
+// exceeds the reference's bin capacity (compute:131).  The thread of bucket slot k then carries its
+// particle's state from the old slot straight to the final one (a scatter inside the cell's range).
+// HALF (sph_step_frame) = also do the first CS_VvHalfStep (compute:309-319) on the way: the same two
+// statements as k_half_step, so positions and velocities are bit-identical to reorder-then-half-step;
+// acceleration is consumed here and density / pressure are dead (the neighbour kernels overwrite all
+// three before anything reads them), so they are not carried over.
+template <bool HALF>
+__global__ __launch_bounds__(kBlock) void k_rank_move(const uint32_t* __restrict__ sortedKeys,
+                                                      const uint32_t* __restrict__ perm,
+                                                      const uint32_t* __restrict__ sid, int n, int cap, float dt,
+                                                      const int* __restrict__ cellCum, StateSet src, StateSet dst,
+                                                      int* __restrict__ counters) {
     int k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= n) return;
-    uint32_t c = sortedKeys[k];
-    int a = cellStart[c], e = cellEnd[c];
-    uint32_t me = sid[k];
+    const uint32_t c = sortedKeys[k];
+    const int a = cellCum[c], e = cellCum[c + 1];
+    const uint32_t me = sid[k];
     int r = 0;
     for (int j = a; j < e; j++) r += (sid[j] < me) ? 1 : 0;
-    perm2[a + r] = perm[k];
-    newOrigId[a + r] = me;
     if (k == a && e - a > cap) atomicAdd(&counters[SPH_CTR_BIN_OVERFLOW], 1);
-}
-
-// state[new slot k] = state[old slot perm2[k]]
-__global__ __launch_bounds__(kBlock) void k_permute_state(int n, const uint32_t* __restrict__ perm2, StateSet src,
-                                                          StateSet dst) {
-    int k = blockIdx.x * kBlock + threadIdx.x;
-    if (k >= n) return;
-    uint32_t s = perm2[k];
-    dst.posM[k] = src.posM[s];
-    dst.velV[k] = src.velV[s];
-    dst.acc[k] = src.acc[s];
-    dst.rhoP[k] = src.rhoP[s];
-    dst.rho0[k] = src.rho0[s];
-}
-
-// sph_step_frame's variant: reorder + the first CS_VvHalfStep (compute:309-319) in one pass.  The
-// half step is the same two statements as k_half_step, so positions and velocities are
-// bit-identical to permute-then-half-step.  Acceleration is consumed here and density / pressure
-// are dead (the neighbour kernels overwrite all three before anything reads them), so they are
-// not carried over: 56 B read + 36 B written per particle instead of 132 + 80.
-__global__ __launch_bounds__(kBlock) void k_permute_half(int n, float dt, const uint32_t* __restrict__ perm2,
-                                                         StateSet src, StateSet dst) {
-    int k = blockIdx.x * kBlock + threadIdx.x;
-    if (k >= n) return;
-    uint32_t s = perm2[k];
+    const uint32_t s = perm[k];
+    const int d = a + r;
     float4 p = src.posM[s], v = src.velV[s];
-    const float4 a = src.acc[s];
-    const float hdt = 0.5f * dt;
-    v.x += hdt * a.x; v.y += hdt * a.y; v.z += hdt * a.z;
-    p.x += v.x * dt; p.y += v.y * dt; p.z += v.z * dt;
-    dst.posM[k] = p;
-    dst.velV[k] = v;
-    dst.rho0[k] = src.rho0[s];
+    if (HALF) {
+        const float4 acc = src.acc[s];
+        const float hdt = 0.5f * dt;
+        v.x += hdt * acc.x; v.y += hdt * acc.y; v.z += hdt * acc.z;
+        p.x += v.x * dt; p.y += v.y * dt; p.z += v.z * dt;
+    } else {
+        dst.acc[d] = src.acc[s];
+        dst.rhoP[d] = src.rhoP[s];
+    }
+    dst.posM[d] = p;
+    dst.velV[d] = v;
+    dst.rho0[d] = src.rho0[s];
+    dst.origId[d] = me;
 }
 
 // cell_of_particle export: keys are per slot and in the tiled memory order; the caller wants the

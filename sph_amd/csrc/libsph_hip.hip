@@ -61,7 +61,6 @@ struct sph_ctx {
     uint32_t* keys[2] = {nullptr, nullptr};
     uint32_t* vals[2] = {nullptr, nullptr};
     uint32_t* sid = nullptr;
-    uint32_t* perm2 = nullptr;
     uint32_t* sortedKeys = nullptr;   // alias into keys[] after the last build
     bool gridValid = false;
     uint32_t* hitMask = nullptr;      // kMaskWords words per slot, written by CS_DensityPressure
@@ -140,7 +139,7 @@ void freeParticles(sph_ctx* c) {
         devFree(c->set[k].rhoP); devFree(c->set[k].rho0); devFree(c->set[k].origId);
         devFree(c->keys[k]); devFree(c->vals[k]);
     }
-    devFree(c->color); devFree(c->phaseOfId); devFree(c->sid); devFree(c->perm2);
+    devFree(c->color); devFree(c->phaseOfId); devFree(c->sid);
     devFree(c->aosStage); devFree(c->recStage); devFree(c->hitMask);
     c->recStageCap = 0;
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -316,12 +315,12 @@ int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
     StateSet dst = c->set[1 - c->cur];
     // velocities of the new order go to the set that does NOT hold the current ones
     dst.velV = c->set[1 - c->velCur].velV;
-    hipLaunchKernelGGL(k_rank_in_cell, dim3(nb), dim3(kBlock), 0, c->stream, c->sortedKeys, perm, c->sid, n, c->cap,
-                       c->cellCum, c->cellCum + 1, c->perm2, dst.origId, c->counters);
-    if (fuseHalfStep)   // sph_step_frame: reorder + first CS_VvHalfStep in one pass
-        hipLaunchKernelGGL(k_permute_half, dim3(nb), dim3(kBlock), 0, c->stream, n, c->dp.dt, c->perm2, src, dst);
+    if (fuseHalfStep)   // sph_step_frame: rank + reorder + first CS_VvHalfStep in one pass
+        hipLaunchKernelGGL(k_rank_move<true>, dim3(nb), dim3(kBlock), 0, c->stream, c->sortedKeys, perm, c->sid, n, c->cap,
+                           c->dp.dt, c->cellCum, src, dst, c->counters);
     else
-        hipLaunchKernelGGL(k_permute_state, dim3(nb), dim3(kBlock), 0, c->stream, n, c->perm2, src, dst);
+        hipLaunchKernelGGL(k_rank_move<false>, dim3(nb), dim3(kBlock), 0, c->stream, c->sortedKeys, perm, c->sid, n, c->cap,
+                           c->dp.dt, c->cellCum, src, dst, c->counters);
     CHECK_LAUNCH(c);
     c->cur = 1 - c->cur;
     c->velCur = 1 - c->velCur;
@@ -461,7 +460,6 @@ static int allocCapacity(sph_ctx* c, int n) {
     if (!rc) rc = devAlloc(c, &c->color, n);
     if (!rc) rc = devAlloc(c, &c->phaseOfId, n);
     if (!rc) rc = devAlloc(c, &c->sid, n);
-    if (!rc) rc = devAlloc(c, &c->perm2, n);
     if (!rc) rc = devAlloc(c, &c->hitMask, (size_t)n * kMaskWords);
     if (!rc) rc = devAlloc(c, &c->aosStage, (size_t)n * SPH_PARTICLE_FLOATS);
     if (rc) { freeParticles(c); return rc; }
