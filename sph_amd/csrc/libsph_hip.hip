@@ -209,7 +209,7 @@ void deriveParams(sph_ctx* c) {
 
 int checkReady(sph_ctx* c, bool needGrid) {
     if (!c) return SPH_E_INVALID;
-    if (c->n <= 0) return fail(c, SPH_E_STATE, "no particles allocated");
+    if (c->n <= 0 && !(c->slab && c->capacity > 0)) return fail(c, SPH_E_STATE, "no particles allocated");
     if (!c->haveParams) return fail(c, SPH_E_STATE, "sph_set_params not called");
     if (c->cells <= 0) return fail(c, SPH_E_STATE, "sph_resize_grid not called");
     deriveParams(c);   // picks up slab / grid changes made after sph_set_params
@@ -295,6 +295,10 @@ int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
     const int nb = blocksFor(n);
     int rc = clearGrid(c, true);
     if (rc) return rc;
+    if (n == 0) {   // an empty slab: the zeroed table is its grid
+        c->gridValid = true;
+        return SPH_OK;
+    }
     StateSet src = curSet(c);
     // keys[0] = cell per old slot, vals[0] = arrival number; keys[1] / vals[1] / sid = key, source slot
     // and id per bucket slot
@@ -331,6 +335,10 @@ int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
 int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false) {
     const int n = c->n;
     c->dp.n = n;
+    if (n == 0 && id != SPH_K_CLEAR_GRID && id != SPH_K_BUILD_GRID) {   // an empty slab has nothing to launch
+        if (id < SPH_K_CLEAR || id > SPH_K_VELOCITY_DAMPING) return fail(c, SPH_E_INVALID, "bad kernel id %d", id);
+        return SPH_OK;
+    }
     const int nb = blocksFor(n);
     StateSet s = curSet(c);
     switch (id) {

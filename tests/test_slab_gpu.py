@@ -15,14 +15,14 @@ from tests.test_slab_gloo import _free_port, small_tank
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, frames, out_dir, n):
+def _worker(rank, world, port, frames, out_dir, n, ghost):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     eng = abi.Engine(0)
     dport = slab.DevicePort(eng, 0, msg_capacity=n)
     comm = slab.NeighbourComm(rank, world, torch.device("cuda", 0), backend="gloo")
-    se = slab.SlabEngine(dport, comm, rank, world, ghost_planes=8)
+    se = slab.SlabEngine(dport, comm, rank, world, ghost_planes=ghost)
     sc = small_tank(se, n=n)
     sc.sph.use_step_frame = True
     sc.start()
@@ -36,8 +36,10 @@ def _worker(rank, world, port, frames, out_dir, n):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
-def test_slabs_equal_single_engine_bitwise(tmp_path, world):
+# (6, 4): six slabs of 8 planes with 4 ghost planes; the outer slabs hold NO particle at first
+# (an empty slab must step like any other) and fill up as the fluid spreads
+@pytest.mark.parametrize("world,ghost", [(1, 8), (2, 8), (3, 8), (6, 4)])
+def test_slabs_equal_single_engine_bitwise(tmp_path, world, ghost):
     frames, n = 8, 3000
     eng = abi.Engine(0)
     sc = small_tank(eng, n=n)
@@ -47,7 +49,7 @@ def test_slabs_equal_single_engine_bitwise(tmp_path, world):
     eng.destroy()
     n = want.shape[0]
 
-    mp.spawn(_worker, args=(world, _free_port(), frames, str(tmp_path), n), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), frames, str(tmp_path), n, ghost), nprocs=world, join=True)
     recs = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)])
     meta = np.load(tmp_path / "meta0.npy")
     assert meta[:-1].tolist() == [n] * frames, "particles not conserved across slabs"
