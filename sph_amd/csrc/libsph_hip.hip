@@ -64,6 +64,9 @@ struct sph_ctx {
     uint32_t* sortedKeys = nullptr;   // alias into keys[] after the last build
     bool gridValid = false;
     uint32_t* hitMask = nullptr;      // kMaskWords words per slot, written by CS_DensityPressure
+    float4* nbrA = nullptr;           // packed neighbour records (PackedNbr), written with the mask
+    float4* nbrB = nullptr;
+    bool packedValid = false;         // nbrA / nbrB match the mask (phase table of <= 4 rows in force)
     bool maskValid = false;           // hitMask matches the current positions and grid
     bool useHitMask = true;           // SPH_HIP_HITMASK=0 turns the hit path off
     int xcdRunOverride = 0;           // SPH_HIP_XCD_RUN=<n> pins the XCD run length (experiments)
@@ -140,7 +143,7 @@ void freeParticles(sph_ctx* c) {
         devFree(c->keys[k]); devFree(c->vals[k]);
     }
     devFree(c->color); devFree(c->phaseOfId); devFree(c->sid);
-    devFree(c->aosStage); devFree(c->recStage); devFree(c->hitMask);
+    devFree(c->aosStage); devFree(c->recStage); devFree(c->hitMask); devFree(c->nbrA); devFree(c->nbrB);
     c->recStageCap = 0;
     if (c->pinned) (void)hipHostFree(c->pinned);
     c->pinned = nullptr; c->pinnedBytes = 0;
@@ -349,22 +352,40 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false)
             return clearGrid(c);
         case SPH_K_BUILD_GRID:
             return buildGrid(c);
-        case SPH_K_DENSITY_PRESSURE:
+        case SPH_K_DENSITY_PRESSURE: {
+            // packed neighbour records: only while every particle's mass / viscosity IS its phase's row
+            const bool packed = c->useHitMask && c->hitMask && !c->slab && c->havePhaseIds && !c->staticDirty &&
+                                !c->phaseTable.empty() && c->phaseTable.size() <= 4;
+            PackedNbr nbr{packed ? c->nbrA : nullptr, c->nbrB, s.velV, s.origId, c->phaseOfId};
             hipLaunchKernelGGL(k_density_pressure_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.rho0,
-                               s.rhoP, c->cellCum, c->counters, c->useHitMask ? c->hitMask : (uint32_t*)nullptr);
+                               s.rhoP, c->cellCum, c->counters, c->useHitMask ? c->hitMask : (uint32_t*)nullptr, nbr);
             c->maskValid = c->useHitMask && c->hitMask;
+            c->packedValid = packed;
             if (c->slab)
                 hipLaunchKernelGGL(k_slab_plane_shift, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, c->sortedKeys,
                                    c->counters);
             break;
+        }
         case SPH_K_FORCE_XSPH: {
             float4* velOut = c->set[1 - c->velCur].velV;
-            if (c->maskValid)
-                hipLaunchKernelGGL(k_force_xsph_hits, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV,
-                                   s.rhoP, s.acc, velOut, c->cellCum, c->counters, c->hitMask, fused ? 1 : 0);
-            else
+            if (c->maskValid && c->packedValid && !c->staticDirty) {
+                float m[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
+                for (size_t k = 0; k < c->phaseTable.size() && k < 4; k++) {
+                    m[k] = c->phaseTable[k].mass;
+                    v[k] = c->phaseTable[k].viscosity;
+                }
+                const PhaseConsts ph{m[0], m[1], m[2], m[3], v[0], v[1], v[2], v[3]};
+                hipLaunchKernelGGL(k_force_xsph_hits<true>, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV,
+                                   s.rhoP, s.acc, velOut, c->cellCum, c->counters, c->hitMask, c->nbrA, c->nbrB, ph,
+                                   fused ? 1 : 0);
+            } else if (c->maskValid) {
+                hipLaunchKernelGGL(k_force_xsph_hits<false>, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV,
+                                   s.rhoP, s.acc, velOut, c->cellCum, c->counters, c->hitMask, (const float4*)nullptr,
+                                   (const float4*)nullptr, PhaseConsts{}, fused ? 1 : 0);
+            } else {
                 hipLaunchKernelGGL(k_force_xsph_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV,
                                    s.rhoP, s.acc, velOut, c->cellCum, c->counters, fused ? 1 : 0);
+            }
             c->velCur = 1 - c->velCur;
             break;
         }
@@ -469,6 +490,8 @@ static int allocCapacity(sph_ctx* c, int n) {
     if (!rc) rc = devAlloc(c, &c->phaseOfId, n);
     if (!rc) rc = devAlloc(c, &c->sid, n);
     if (!rc) rc = devAlloc(c, &c->hitMask, (size_t)n * kMaskWords);
+    if (!rc) rc = devAlloc(c, &c->nbrA, (size_t)n);
+    if (!rc) rc = devAlloc(c, &c->nbrB, (size_t)n);
     if (!rc) rc = devAlloc(c, &c->aosStage, (size_t)n * SPH_PARTICLE_FLOATS);
     if (rc) { freeParticles(c); return rc; }
     c->capacity = n;

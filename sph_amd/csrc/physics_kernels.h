@@ -90,6 +90,24 @@ __device__ __forceinline__ RowRange range_at(const DevParams& P, const int* __re
     return r;
 }
 
+// What the force kernel needs from a NEIGHBOUR is ten floats -- position, velocity, density, pressure,
+// mass, viscosity -- i.e. three scattered gathers per in-range pair, and that kernel is bound by the
+// texture addresser's gather rate (~32 clk per wave-wide scattered load, measured), not by arithmetic
+// or HBM.  Mass and viscosity are per-PHASE constants in the reference (SPH.cs:284-298 rewrites them
+// from the spawn box of every particle each frame), so when the caller has given a phase table of at
+// most four rows the density kernel leaves two 16-byte records per particle,
+//     a = (x, y, z, density | phase bit 0 in the sign)    b = (vx, vy, vz, pressure | phase bit 1 in the sign)
+// (density > 0 and Tait pressure >= 0 because density >= rest density, so the signs are free), and the
+// force kernel does two gathers per pair and looks mass / viscosity up by phase: same bits, 1/3 fewer gathers.
+struct PackedNbr {
+    float4* a;                       // null = not in use
+    float4* b;
+    const float4* velV;
+    const uint32_t* origId;
+    const uint8_t* phaseOfId;
+};
+struct PhaseConsts { float m0, m1, m2, m3, v0, v1, v2, v3; };   // named, not arrays: selects must stay v_cndmask, not indexed loads
+
 // CS_DensityPressure (compute:142-193), fast path.  Same operations in the same order as the
 // per-cell kernel below, so the density is bit-identical to the oracle's.
 __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, const float4* __restrict__ posM,
@@ -97,12 +115,15 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
                                                                   float2* __restrict__ rhoP,
                                                                   const int* __restrict__ cellCum,
                                                                   const int* __restrict__ counters,
-                                                                  uint32_t* __restrict__ hitMask) {
+                                                                  uint32_t* __restrict__ hitMask, PackedNbr nbr) {
     const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
     const int nRanges = capped ? 27 : 9;
     const int s = xcd_tile(blockIdx.x, gridDim.x, P.xcdRun) * kBlock + threadIdx.x;
     if (s >= P.n) return;
     const float4 p = posM[s];
+    // (for the packed neighbour records written at the end; loaded here so the latency is hidden)
+    const uint32_t ph = nbr.a ? nbr.phaseOfId[nbr.origId[s]] : 0u;
+    const float4 v = nbr.a ? nbr.velV[s] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int3 c = search_cell(P, p.x, p.y, p.z);
     float density = 0.0f;
     // Hit mask for the force kernel (see k_force_xsph_hits): one bit per candidate slot, every row
@@ -187,6 +208,11 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
     const float localB = r0 * (P.soundSpeed * P.soundSpeed) / P.gamma;     // compute:189
     const float pressure = localB * (powf(density / r0, P.gamma) - 1.0f);  // compute:190
     rhoP[s] = make_float2(density, pressure);
+    if (recording && nbr.a) {
+        // see PackedNbr: the phase id rides in the sign bits of density (> 0) and pressure (>= 0)
+        nbr.a[s] = make_float4(p.x, p.y, p.z, __uint_as_float(__float_as_uint(density) | ((ph & 1u) << 31)));
+        nbr.b[s] = make_float4(v.x, v.y, v.z, __uint_as_float(__float_as_uint(pressure) | ((ph & 2u) << 30)));
+    }
 }
 
 // One in-range pair of CS_ForceXSPH (compute:250-277) with explicit FMAs and hardware
@@ -374,13 +400,17 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_rows(DevParams P, const f
 // k_density_pressure_rows on exactly these positions and this grid.  A wave falls back to the scan
 // path if a bin overflowed (27 capped ranges, no mask) or any of its particles needs more mask words
 // than a row holds.
+template <bool PACKED>
 __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const float4* __restrict__ posM,
                                                             const float4* __restrict__ velIn,
                                                             const float2* __restrict__ rhoP,
                                                             float4* __restrict__ acc, float4* __restrict__ velOut,
                                                             const int* __restrict__ cellCum,
                                                             const int* __restrict__ counters,
-                                                            const uint32_t* __restrict__ hitMask, int zeroDeadAcc) {
+                                                            const uint32_t* __restrict__ hitMask,
+                                                            const float4* __restrict__ nbrA,
+                                                            const float4* __restrict__ nbrB, PhaseConsts ph,
+                                                            int zeroDeadAcc) {
     // one buffer, two uses: (a) per lane the non-empty mask words and the slot of their bit 0,
     // (b) the scan path's hit FIFO.  Every thread only touches its own column.
     static_assert(2 * kMaskWords >= kHitQueue, "the FIFO lives in the word list's LDS");
@@ -455,10 +485,24 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
             int j0, j1;
             S.h0 = pop(j0);
             S.h1 = pop(j1);
-            S.q0 = posM[j0]; S.u0 = velIn[j0]; S.o0 = rhoP[j0];
-            S.q1 = posM[j1]; S.u1 = velIn[j1]; S.o1 = rhoP[j1];
+            if (PACKED) {
+                S.q0 = nbrA[j0]; S.u0 = nbrB[j0];
+                S.q1 = nbrA[j1]; S.u1 = nbrB[j1];
+            } else {
+                S.q0 = posM[j0]; S.u0 = velIn[j0]; S.o0 = rhoP[j0];
+                S.q1 = posM[j1]; S.u1 = velIn[j1]; S.o1 = rhoP[j1];
+            }
         };
-        auto compute = [&](const Stage& S) {
+        auto unpack = [&](float4& q, float4& u, float2& o) {
+            const bool b0 = (__float_as_uint(q.w) >> 31) != 0, b1 = (__float_as_uint(u.w) >> 31) != 0;
+            o = make_float2(fabsf(q.w), fabsf(u.w));
+            const float mLo = b0 ? ph.m1 : ph.m0, mHi = b0 ? ph.m3 : ph.m2;
+            const float vLo = b0 ? ph.v1 : ph.v0, vHi = b0 ? ph.v3 : ph.v2;
+            q.w = b1 ? mHi : mLo;
+            u.w = b1 ? vHi : vLo;
+        };
+        auto compute = [&](Stage& S) {
+            if (PACKED) { unpack(S.q0, S.u0, S.o0); unpack(S.q1, S.u1, S.o1); }
             if (S.h0) force_pair(P, A, me.p, me.v, me.densitySelf, me.selfTerm, S.q0, S.u0, S.o0);
             if (S.h1) force_pair(P, A, me.p, me.v, me.densitySelf, me.selfTerm, S.q1, S.u1, S.o1);
         };

@@ -86,3 +86,29 @@ def test_force_dispatch_without_a_fresh_mask():
         e.dispatch(abi.K_FORCE_XSPH, n)
     assert_fields_close(eng.download_particles(), ora.download_particles(), 1e-5, "stale mask: ")
     eng.destroy(); ora.destroy()
+
+
+def test_live_phase_edit_lockstep():
+    """SPH.cs:284-298 re-applies the spawn boxes' restDensity / viscosity / mass every frame, so editing
+    a box mid-run changes the particles of that phase.  The engine's packed neighbour records look
+    mass and viscosity up by phase: they must follow the edit exactly like the oracle's per-particle
+    fields do."""
+    from oracle.ora import Oracle
+    eng, ora = abi.Engine(0), Oracle()
+    se, so = scenes.unity_scene(eng, which=4, scale_count=0.03), scenes.unity_scene(ora, which=4, scale_count=0.03)
+    se.sph.use_step_frame = True
+    se.start(); so.start()
+    for f in range(6):
+        if f == 2:
+            for sc in (se, so):
+                sc.sph.spawnBoxes[1].particleMass = 0.25
+                sc.sph.spawnBoxes[1].viscosity = 0.07
+        if f == 4:
+            for sc in (se, so):
+                sc.sph.spawnBoxes[0].viscosity = 0.2
+        eng.upload_particles(ora.download_particles())
+        se.frame(); so.frame()
+        pe, po = eng.download_particles(), ora.download_particles()
+        assert np.array_equal(pe[:, 11:14], po[:, 11:14]), f"frame {f}: static fields"
+        assert_fields_close(pe, po, 1e-5, f"frame {f}: ")
+    eng.destroy(); ora.destroy()
