@@ -338,14 +338,15 @@ SLAB_RECORD_DTYPE = np.dtype([("pos", np.float32, 3), ("mass", np.float32), ("ve
 assert SLAB_RECORD_DTYPE.itemsize == SLAB_RECORD_BYTES
 
 
-def records_from_aos(aos: np.ndarray, ids: np.ndarray) -> np.ndarray:
-    """72-byte AoS rows (+ global ids) -> slab records."""
+def records_from_aos(aos: np.ndarray, ids: np.ndarray, phase=0) -> np.ndarray:
+    """72-byte AoS rows (+ global ids, + phase = spawn box index, scalar or per row) -> slab records."""
     aos = np.asarray(aos, dtype=np.float32).reshape(-1, PARTICLE_FLOATS)
     r = np.zeros(aos.shape[0], dtype=SLAB_RECORD_DTYPE)
     r["pos"], r["vel"], r["acc"] = aos[:, 0:3], aos[:, 3:6], aos[:, 6:9]
     r["density"], r["pressure"], r["restDensity"] = aos[:, 9], aos[:, 10], aos[:, 11]
     r["viscosity"], r["mass"] = aos[:, 12], aos[:, 13]
     r["id"] = ids
+    r["phase"] = phase
     return r
 
 

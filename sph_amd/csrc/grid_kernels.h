@@ -203,6 +203,7 @@ __global__ __launch_bounds__(kBlock) void k_rank_move(const uint32_t* __restrict
     dst.velV[d] = v;
     dst.rho0[d] = src.rho0[s];
     dst.origId[d] = me;
+    if (src.phase) dst.phase[d] = src.phase[s];
 }
 
 // cell_of_particle export: keys are per slot and in the tiled memory order; the caller wants the

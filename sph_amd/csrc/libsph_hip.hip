@@ -70,13 +70,20 @@ struct sph_ctx {
     bool maskValid = false;           // hitMask matches the current positions and grid
     bool useHitMask = true;           // SPH_HIP_HITMASK=0 turns the hit path off
     int xcdRunOverride = 0;           // SPH_HIP_XCD_RUN=<n> pins the XCD run length (experiments)
+    bool debug = false;               // SPH_HIP_DEBUG=1: report on stderr which force kernel runs
+    int lastForceVariant = -1;
 
     int* counters = nullptr;          // SPH_CTR_COUNT ints on the device
+    int* hostInts = nullptr;          // 16 pinned ints: landing zone of the small device -> host reads
 
     // slab decomposition (multi-GPU)
     bool slab = false;
     int rxGlobal = 0, xOffset = 0, ownLoG = 0, ownHiG = 0;   // global plane coordinates
     int* slabCounts = nullptr;        // 4 ints on the device (message / rebuild counters)
+    int* blockInts = nullptr;         // one int per workgroup: collision counts of the boundary kernels; slab
+                                      // mode: plane shifts of the density kernel (capacity / 256 + 1 ints)
+    int* phaseMismatch = nullptr;     // device flag: some slab record's statics are not its phase's row (PhaseCheck)
+    bool slabPackedOff = false;       // the phase table changed after the records were uploaded
     SlabRecord* recStage = nullptr;   // device staging for slab upload / download
     size_t recStageCap = 0;
     float* aosStage = nullptr;        // device AoS staging (n * 72 B)
@@ -139,11 +146,11 @@ void devFree(T*& p) {
 void freeParticles(sph_ctx* c) {
     for (int k = 0; k < 2; k++) {
         devFree(c->set[k].posM); devFree(c->set[k].velV); devFree(c->set[k].acc);
-        devFree(c->set[k].rhoP); devFree(c->set[k].rho0); devFree(c->set[k].origId);
+        devFree(c->set[k].rhoP); devFree(c->set[k].rho0); devFree(c->set[k].origId); devFree(c->set[k].phase);
         devFree(c->keys[k]); devFree(c->vals[k]);
     }
     devFree(c->color); devFree(c->phaseOfId); devFree(c->sid);
-    devFree(c->aosStage); devFree(c->recStage); devFree(c->hitMask); devFree(c->nbrA); devFree(c->nbrB);
+    devFree(c->aosStage); devFree(c->recStage); devFree(c->blockInts); devFree(c->hitMask); devFree(c->nbrA); devFree(c->nbrB);
     c->recStageCap = 0;
     if (c->pinned) (void)hipHostFree(c->pinned);
     c->pinned = nullptr; c->pinnedBytes = 0;
@@ -231,6 +238,15 @@ int checkReady(sph_ctx* c, bool needGrid) {
     c->dp.n = c->n;
     if (!(c->dp.cellSize > 0.0f)) return fail(c, SPH_E_INVALID, "cellSize must be > 0");
     if (needGrid && !c->gridValid) return fail(c, SPH_E_STATE, "grid not built (dispatch CS_BuildGrid first)");
+    return SPH_OK;
+}
+
+// n <= 16 ints from the device, through pinned memory (a pageable destination makes the runtime stage
+// the copy and costs ~0.1 ms per read); synchronises the stream.
+int readInts(sph_ctx* c, const int* dev, int n, int* out) {
+    HIP_TRY(c, hipMemcpyAsync(c->hostInts, dev, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < n; k++) out[k] = c->hostInts[k];
     return SPH_OK;
 }
 
@@ -354,21 +370,35 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false)
             return buildGrid(c);
         case SPH_K_DENSITY_PRESSURE: {
             // packed neighbour records: only while every particle's mass / viscosity IS its phase's row
-            const bool packed = c->useHitMask && c->hitMask && !c->slab && c->havePhaseIds && !c->staticDirty &&
-                                !c->phaseTable.empty() && c->phaseTable.size() <= 4;
-            PackedNbr nbr{packed ? c->nbrA : nullptr, c->nbrB, s.velV, s.origId, c->phaseOfId};
+            // (one GPU: the table has been applied; slab mode: the records came with phase ids and the
+            // table has not changed since -- records that disagree with it raise phaseMismatch)
+            const bool tableOk = !c->phaseTable.empty() && c->phaseTable.size() <= 4;
+            const bool packed = c->useHitMask && c->hitMask && tableOk &&
+                                (c->slab ? (s.phase != nullptr && !c->slabPackedOff) : (c->havePhaseIds && !c->staticDirty));
+            PackedNbr nbr{packed ? c->nbrA : nullptr, c->nbrB, s.velV, s.origId, c->phaseOfId,
+                          c->slab ? (const uint8_t*)s.phase : (const uint8_t*)nullptr};
             hipLaunchKernelGGL(k_density_pressure_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.rho0,
-                               s.rhoP, c->cellCum, c->counters, c->useHitMask ? c->hitMask : (uint32_t*)nullptr, nbr);
+                               s.rhoP, c->cellCum, c->counters, c->useHitMask ? c->hitMask : (uint32_t*)nullptr, nbr,
+                               c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr, c->blockInts);
+            if (c->slab)
+                hipLaunchKernelGGL(k_slab_shift_reduce, dim3(1), dim3(kBlock), 0, c->stream, c->blockInts, nb,
+                                   c->counters + SPH_CTR_MAX_PLANE_SHIFT);
             c->maskValid = c->useHitMask && c->hitMask;
             c->packedValid = packed;
-            if (c->slab)
-                hipLaunchKernelGGL(k_slab_plane_shift, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, c->sortedKeys,
-                                   c->counters);
             break;
         }
         case SPH_K_FORCE_XSPH: {
             float4* velOut = c->set[1 - c->velCur].velV;
-            if (c->maskValid && c->packedValid && !c->staticDirty) {
+            if (c->debug) {
+                const int variant = !c->maskValid ? 0 : (c->packedValid && (c->slab ? !c->slabPackedOff : !c->staticDirty)) ? 2 : 1;
+                if (variant != c->lastForceVariant) {
+                    static const char* const names[3] = {"k_force_xsph_rows (scan)", "k_force_xsph_hits (hit mask, three gathers)",
+                                                         "k_force_xsph_hits (hit mask, packed neighbour records)"};
+                    fprintf(stderr, "[libsph_hip] CS_ForceXSPH -> %s%s\n", names[variant], c->slab ? " [slab]" : "");
+                    c->lastForceVariant = variant;
+                }
+            }
+            if (c->maskValid && c->packedValid && (c->slab ? !c->slabPackedOff : !c->staticDirty)) {
                 float m[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
                 for (size_t k = 0; k < c->phaseTable.size() && k < 4; k++) {
                     m[k] = c->phaseTable[k].mass;
@@ -377,11 +407,11 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false)
                 const PhaseConsts ph{m[0], m[1], m[2], m[3], v[0], v[1], v[2], v[3]};
                 hipLaunchKernelGGL(k_force_xsph_hits<true>, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV,
                                    s.rhoP, s.acc, velOut, c->cellCum, c->counters, c->hitMask, c->nbrA, c->nbrB, ph,
-                                   fused ? 1 : 0);
+                                   c->slab ? (const int*)c->phaseMismatch : (const int*)nullptr, fused ? 1 : 0);
             } else if (c->maskValid) {
                 hipLaunchKernelGGL(k_force_xsph_hits<false>, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV,
                                    s.rhoP, s.acc, velOut, c->cellCum, c->counters, c->hitMask, (const float4*)nullptr,
-                                   (const float4*)nullptr, PhaseConsts{}, fused ? 1 : 0);
+                                   (const float4*)nullptr, PhaseConsts{}, (const int*)nullptr, fused ? 1 : 0);
             } else {
                 hipLaunchKernelGGL(k_force_xsph_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV,
                                    s.rhoP, s.acc, velOut, c->cellCum, c->counters, fused ? 1 : 0);
@@ -397,16 +427,20 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false)
             if (fused) {   // + CS_BoundObs (+ CS_VelocityDamping after the last sub-step), one pass
                 c->maskValid = false;
                 hipLaunchKernelGGL(k_full_bound_damp, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, s.acc,
-                                   c->counters, c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr,
+                                   c->blockInts, c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr,
                                    lastSub ? 1 : 0);
+                hipLaunchKernelGGL(k_sum_into, dim3(1), dim3(kBlock), 0, c->stream, c->blockInts, nb,
+                                   c->counters + SPH_CTR_COLLISIONS);
                 break;
             }
             hipLaunchKernelGGL(k_full_step, dim3(nb), dim3(kBlock), 0, c->stream, n, c->dp.dt, s.velV, s.acc);
             break;
         case SPH_K_BOUND_OBS:
             c->maskValid = false;
-            hipLaunchKernelGGL(k_bound_obs, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, c->counters,
+            hipLaunchKernelGGL(k_bound_obs, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, c->blockInts,
                                c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr);
+            hipLaunchKernelGGL(k_sum_into, dim3(1), dim3(kBlock), 0, c->stream, c->blockInts, nb,
+                               c->counters + SPH_CTR_COLLISIONS);
             break;
         case SPH_K_VELOCITY_DAMPING:
             hipLaunchKernelGGL(k_velocity_damping, dim3(nb), dim3(kBlock), 0, c->stream, n, s.velV);
@@ -438,14 +472,18 @@ int sph_create(sph_ctx** out, int device_id) {
     if (const char* tl = getenv("SPH_HIP_TIMING")) c->timingLevel = atoi(tl);
     if (const char* hm = getenv("SPH_HIP_HITMASK")) c->useHitMask = atoi(hm) != 0;
     if (const char* xr = getenv("SPH_HIP_XCD_RUN")) c->xcdRunOverride = atoi(xr);
+    if (const char* dbg = getenv("SPH_HIP_DEBUG")) c->debug = atoi(dbg) != 0;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return SPH_E_HIP;
     }
     for (int r = 0; r < kTimingRing; r++)
         for (int k = 0; k < kNumEvents; k++) (void)hipEventCreate(&c->ev[r][k]);
-    if (hipMalloc((void**)&c->counters, SPH_CTR_COUNT * sizeof(int)) != hipSuccess ||
+    if (hipHostMalloc((void**)&c->hostInts, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void**)&c->counters, SPH_CTR_COUNT * sizeof(int)) != hipSuccess ||
         hipMalloc((void**)&c->slabCounts, 4 * sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&c->phaseMismatch, sizeof(int)) != hipSuccess ||
+        hipMemsetAsync(c->phaseMismatch, 0, sizeof(int), c->stream) != hipSuccess ||
         hipMemsetAsync(c->counters, 0, SPH_CTR_COUNT * sizeof(int), c->stream) != hipSuccess) {
         sph_destroy(c);
         return SPH_E_NOMEM;
@@ -461,7 +499,10 @@ int sph_destroy(sph_ctx* c) {
     freeParticles(c);
     freeGrid(c);
     devFree(c->counters);
+    if (c->hostInts) (void)hipHostFree(c->hostInts);
+    c->hostInts = nullptr;
     devFree(c->slabCounts);
+    devFree(c->phaseMismatch);
     devFree(c->phaseTableDev);
     for (int r = 0; r < kTimingRing; r++)
         for (int k = 0; k < kNumEvents; k++)
@@ -483,12 +524,14 @@ static int allocCapacity(sph_ctx* c, int n) {
         if (!rc) rc = devAlloc(c, &c->set[k].rhoP, n);
         if (!rc) rc = devAlloc(c, &c->set[k].rho0, n);
         if (!rc) rc = devAlloc(c, &c->set[k].origId, n);
+        if (!rc && c->slab) rc = devAlloc(c, &c->set[k].phase, n);   // phases travel by slot in slab mode
         if (!rc) rc = devAlloc(c, &c->keys[k], n);
         if (!rc) rc = devAlloc(c, &c->vals[k], n);
     }
     if (!rc) rc = devAlloc(c, &c->color, n);
     if (!rc) rc = devAlloc(c, &c->phaseOfId, n);
     if (!rc) rc = devAlloc(c, &c->sid, n);
+    if (!rc) rc = devAlloc(c, &c->blockInts, (size_t)blocksFor(n) + 1);
     if (!rc) rc = devAlloc(c, &c->hitMask, (size_t)n * kMaskWords);
     if (!rc) rc = devAlloc(c, &c->nbrA, (size_t)n);
     if (!rc) rc = devAlloc(c, &c->nbrB, (size_t)n);
@@ -606,6 +649,9 @@ int sph_set_phase_table(sph_ctx* c, const sph_phase* table, int n_phases) {
         return SPH_OK;   // unchanged since last frame: nothing to re-apply
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // slab records carry their own static properties: a table that changes under them no longer
+    // describes them (no live phase edits in slab mode), so the packed neighbour records go off
+    if (c->slab && c->n > 0) c->slabPackedOff = true;
     if ((int)c->phaseTable.size() != n_phases) {
         devFree(c->phaseTableDev);
         int rc = devAlloc(c, &c->phaseTableDev, (size_t)n_phases);
@@ -717,8 +763,7 @@ int sph_read_counter(sph_ctx* c, int which, int* value) {
     if (!c) return SPH_E_INVALID;
     if (which < 0 || which >= SPH_CTR_COUNT || !value) return fail(c, SPH_E_INVALID, "bad counter %d", which);
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMemcpyAsync(value, c->counters + which, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int rcRead = readInts(c, c->counters + which, 1, value)) return rcRead;
     return SPH_OK;
 }
 
@@ -873,6 +918,11 @@ int sph_slab_reserve(sph_ctx* c, int capacity) {
     return SPH_OK;
 }
 
+static PhaseCheck phaseCheck(sph_ctx* c) {
+    return PhaseCheck{c->phaseTable.empty() ? (const sph_phase*)nullptr : (const sph_phase*)c->phaseTableDev,
+                      (int)c->phaseTable.size(), c->phaseMismatch};
+}
+
 static int ensureRecStage(sph_ctx* c, size_t n) {
     if (n <= c->recStageCap) return SPH_OK;
     devFree(c->recStage);
@@ -896,11 +946,14 @@ int sph_slab_upload(sph_ctx* c, const sph_slab_record* records, int n) {
     }
     c->cur = 0; c->velCur = 0; c->gridValid = false; c->maskValid = false;
     c->n = n;
+    c->slabPackedOff = false;
+    HIP_TRY(c, hipMemsetAsync(c->phaseMismatch, 0, sizeof(int), c->stream));
     if (n == 0) return SPH_OK;
     int rc = ensureRecStage(c, (size_t)n);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpy(c->recStage, records, sizeof(SlabRecord) * (size_t)n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_slab_import, dim3(blocksFor(n)), dim3(kBlock), 0, c->stream, n, c->recStage, c->set[0]);
+    hipLaunchKernelGGL(k_slab_import, dim3(blocksFor(n)), dim3(kBlock), 0, c->stream, n, c->recStage, c->set[0],
+                       phaseCheck(c));
     CHECK_LAUNCH(c);
     return SPH_OK;
 }
@@ -922,8 +975,7 @@ int sph_slab_download(sph_ctx* c, sph_slab_record* records, int max_records, int
                        c->n, c->slabCounts);
     CHECK_LAUNCH(c);
     int cnt = 0;
-    HIP_TRY(c, hipMemcpyAsync(&cnt, c->slabCounts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int rcRead = readInts(c, c->slabCounts, 1, &cnt)) return rcRead;
     if (cnt > max_records) return fail(c, SPH_E_INVALID, "%d records do not fit %d", cnt, max_records);
     if (cnt > 0) HIP_TRY(c, hipMemcpy(records, c->recStage, sizeof(SlabRecord) * (size_t)cnt, hipMemcpyDeviceToHost));
     *n_out = cnt;
@@ -947,8 +999,7 @@ int sph_slab_pack(sph_ctx* c, int left_below, int right_from, void* dev_left, in
                        (SlabRecord*)dev_left, cap_left, (SlabRecord*)dev_right, cap_right, c->slabCounts);
     CHECK_LAUNCH(c);
     int cnt[2] = {0, 0};
-    HIP_TRY(c, hipMemcpyAsync(cnt, c->slabCounts, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int rcRead = readInts(c, c->slabCounts, 2, cnt)) return rcRead;
     *n_left = cnt[0];
     *n_right = cnt[1];
     if (cnt[0] > cap_left || cnt[1] > cap_right)
@@ -970,20 +1021,20 @@ int sph_slab_rebuild(sph_ctx* c, int keep_lo, int keep_hi, const void* dev_from_
     dst.velV = c->set[1 - c->velCur].velV;
     HIP_TRY(c, hipMemsetAsync(c->slabCounts, 0, 4 * sizeof(int), c->stream));
     if (c->n > 0)
-        hipLaunchKernelGGL(k_slab_keep, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->dp, src,
+        hipLaunchKernelGGL(k_slab_keep, dim3((c->n + kBlock * kKeepItems - 1) / (kBlock * kKeepItems)), dim3(kBlock), 0, c->stream, c->dp, src,
                            c->gridValid ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr, keep_lo, keep_hi, dst,
                            c->capacity, c->slabCounts);
     if (n_from_left > 0)
         hipLaunchKernelGGL(k_slab_append, dim3(blocksFor(n_from_left)), dim3(kBlock), 0, c->stream, c->dp,
-                           (const SlabRecord*)dev_from_left, n_from_left, keep_lo, keep_hi, dst, c->capacity, c->slabCounts);
+                           (const SlabRecord*)dev_from_left, n_from_left, keep_lo, keep_hi, dst, c->capacity, c->slabCounts,
+                           phaseCheck(c));
     if (n_from_right > 0)
         hipLaunchKernelGGL(k_slab_append, dim3(blocksFor(n_from_right)), dim3(kBlock), 0, c->stream, c->dp,
                            (const SlabRecord*)dev_from_right, n_from_right, keep_lo, keep_hi, dst, c->capacity,
-                           c->slabCounts);
+                           c->slabCounts, phaseCheck(c));
     CHECK_LAUNCH(c);
     int cnt = 0;
-    HIP_TRY(c, hipMemcpyAsync(&cnt, c->slabCounts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (int rcRead = readInts(c, c->slabCounts, 1, &cnt)) return rcRead;
     if (cnt > c->capacity) return fail(c, SPH_E_NOMEM, "slab population %d exceeds the reserved capacity %d", cnt, c->capacity);
     c->cur = 1 - c->cur;
     c->velCur = 1 - c->velCur;

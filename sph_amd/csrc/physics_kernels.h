@@ -104,7 +104,8 @@ struct PackedNbr {
     float4* b;
     const float4* velV;
     const uint32_t* origId;
-    const uint8_t* phaseOfId;
+    const uint8_t* phaseOfId;        // phases by particle id ...
+    const uint8_t* phaseOfSlot;      // ... or by slot (slab mode); one of the two
 };
 struct PhaseConsts { float m0, m1, m2, m3, v0, v1, v2, v3; };   // named, not arrays: selects must stay v_cndmask, not indexed loads
 
@@ -115,14 +116,32 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
                                                                   float2* __restrict__ rhoP,
                                                                   const int* __restrict__ cellCum,
                                                                   const int* __restrict__ counters,
-                                                                  uint32_t* __restrict__ hitMask, PackedNbr nbr) {
+                                                                  uint32_t* __restrict__ hitMask, PackedNbr nbr,
+                                                                  const uint32_t* __restrict__ slabKeys,
+                                                                  int* __restrict__ slabShift) {
     const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
     const int nRanges = capped ? 27 : 9;
     const int s = xcd_tile(blockIdx.x, gridDim.x, P.xcdRun) * kBlock + threadIdx.x;
-    if (s >= P.n) return;
-    const float4 p = posM[s];
+    const bool valid = s < P.n;
+    const float4 p = posM[valid ? s : 0];
+    if (slabKeys) {
+        // slab mode: how many planes has the particle moved since it was binned?  The halo width the
+        // driver needs follows from the maximum (SPH_CTR_MAX_PLANE_SHIFT).  Every workgroup stores its
+        // own maximum; k_slab_shift_reduce folds them.  (One atomic per WAVE on the counter -- even
+        // behind a check -- serialises 32 k requests on one address: +70 us at 2 M particles.)
+        __shared__ int waveShift[kBlock / 64];
+        const int cx = search_cell(P, p.x, p.y, p.z).x;
+        int shift = valid ? abs(cx - ((int)(slabKeys[s] % (uint32_t)P.rx) + P.xoff)) : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) shift = max(shift, __shfl_xor(shift, o));
+        if ((threadIdx.x & 63) == 0) waveShift[threadIdx.x >> 6] = shift;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            slabShift[blockIdx.x] = max(max(waveShift[0], waveShift[1]), max(waveShift[2], waveShift[3]));
+    }
+    if (!valid) return;
     // (for the packed neighbour records written at the end; loaded here so the latency is hidden)
-    const uint32_t ph = nbr.a ? nbr.phaseOfId[nbr.origId[s]] : 0u;
+    const uint32_t ph = !nbr.a ? 0u : nbr.phaseOfSlot ? nbr.phaseOfSlot[s] : nbr.phaseOfId[nbr.origId[s]];
     const float4 v = nbr.a ? nbr.velV[s] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int3 c = search_cell(P, p.x, p.y, p.z);
     float density = 0.0f;
@@ -213,6 +232,19 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
         nbr.a[s] = make_float4(p.x, p.y, p.z, __uint_as_float(__float_as_uint(density) | ((ph & 1u) << 31)));
         nbr.b[s] = make_float4(v.x, v.y, v.z, __uint_as_float(__float_as_uint(pressure) | ((ph & 2u) << 30)));
     }
+}
+
+// slab mode: maximum of the per-workgroup plane shifts left by the density kernel
+__global__ __launch_bounds__(kBlock) void k_slab_shift_reduce(const int* __restrict__ blockShift, int nBlocks,
+                                                              int* __restrict__ counter) {
+    __shared__ int ws[kBlock / 64];
+    int m = 0;
+    for (int b = threadIdx.x; b < nBlocks; b += kBlock) m = max(m, blockShift[b]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(counter, max(max(ws[0], ws[1]), max(ws[2], ws[3])));
 }
 
 // One in-range pair of CS_ForceXSPH (compute:250-277) with explicit FMAs and hardware
@@ -410,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
                                                             const uint32_t* __restrict__ hitMask,
                                                             const float4* __restrict__ nbrA,
                                                             const float4* __restrict__ nbrB, PhaseConsts ph,
-                                                            int zeroDeadAcc) {
+                                                            const int* __restrict__ phaseMismatch, int zeroDeadAcc) {
     // one buffer, two uses: (a) per lane the non-empty mask words and the slot of their bit 0,
     // (b) the scan path's hit FIFO.  Every thread only touches its own column.
     static_assert(2 * kMaskWords >= kHitQueue, "the FIFO lives in the word list's LDS");
@@ -459,6 +491,8 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
                 }
             }
         }
+        // (slab mode: a record whose mass / viscosity is not its phase's row switches the packed path off)
+        const bool packed = PACKED && (!phaseMismatch || *phaseMismatch == 0);
         // 3) walk the set bits: visiting order, one add per hit to find its slot
         int li = 0, base = 0;
         uint32_t w = 0;
@@ -485,7 +519,7 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
             int j0, j1;
             S.h0 = pop(j0);
             S.h1 = pop(j1);
-            if (PACKED) {
+            if (packed) {
                 S.q0 = nbrA[j0]; S.u0 = nbrB[j0];
                 S.q1 = nbrA[j1]; S.u1 = nbrB[j1];
             } else {
@@ -502,7 +536,7 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
             u.w = b1 ? vHi : vLo;
         };
         auto compute = [&](Stage& S) {
-            if (PACKED) { unpack(S.q0, S.u0, S.o0); unpack(S.q1, S.u1, S.o1); }
+            if (packed) { unpack(S.q0, S.u0, S.o0); unpack(S.q1, S.u1, S.o1); }
             if (S.h0) force_pair(P, A, me.p, me.v, me.densitySelf, me.selfTerm, S.q0, S.u0, S.o0);
             if (S.h1) force_pair(P, A, me.p, me.v, me.densitySelf, me.selfTerm, S.q1, S.u1, S.o1);
         };
@@ -638,10 +672,34 @@ __device__ __forceinline__ bool slot_is_owned(const DevParams& P, const uint32_t
     return plane >= P.ownLo && plane < P.ownHi;
 }
 
-// CS_BoundObs kernel.  The per-collision InterlockedAdd (compute:418) becomes one wave ballot +
-// popcount and a single atomic per wave; in slab mode ghost copies are counted by their owner.
+// The per-collision InterlockedAdd (compute:418) becomes a count per WORKGROUP (wave ballots + LDS),
+// stored -- not added -- into blockCount[workgroup]; k_sum_into folds the counts into the counter.  Even
+// one atomic per wave on the counter serialises on its address (~2 ns each): in a settled tank, where
+// most waves have a particle touching a wall, that tripled the time of the fused tail kernel.
+__device__ __forceinline__ void block_count(bool pred, int* __restrict__ blockCount) {
+    __shared__ int waveCnt[kBlock / 64];
+    const unsigned long long m = __ballot(pred);
+    if ((threadIdx.x & 63) == 0) waveCnt[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) blockCount[blockIdx.x] = (waveCnt[0] + waveCnt[1]) + (waveCnt[2] + waveCnt[3]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_sum_into(const int* __restrict__ blockCount, int nBlocks,
+                                                     int* __restrict__ counter) {
+    __shared__ int ws[kBlock / 64];
+    int m = 0;
+    for (int b = threadIdx.x; b < nBlocks; b += kBlock) m += blockCount[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const int tot = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+    if (threadIdx.x == 0 && tot) atomicAdd(counter, tot);
+}
+
+// CS_BoundObs kernel; in slab mode ghost copies are counted by their owner.
 __global__ __launch_bounds__(kBlock) void k_bound_obs(DevParams P, float4* __restrict__ posM,
-                                                      float4* __restrict__ velV, int* __restrict__ counters,
+                                                      float4* __restrict__ velV, int* __restrict__ blockCount,
                                                       const uint32_t* __restrict__ sortedKeys) {
     int s = blockIdx.x * kBlock + threadIdx.x;
     bool collided = false;
@@ -651,8 +709,7 @@ __global__ __launch_bounds__(kBlock) void k_bound_obs(DevParams P, float4* __res
         posM[s] = p;
         velV[s] = v;
     }
-    const unsigned long long m = __ballot(collided);
-    if (m && (threadIdx.x & 63) == 0) atomicAdd(&counters[SPH_CTR_COLLISIONS], __popcll(m));
+    block_count(collided, blockCount);
 }
 
 __device__ __forceinline__ void damp_velocity(float4& v) {                 // compute:499-507
@@ -667,7 +724,7 @@ __device__ __forceinline__ void damp_velocity(float4& v) {                 // co
 __global__ __launch_bounds__(kBlock) void k_full_bound_damp(DevParams P, float4* __restrict__ posM,
                                                             float4* __restrict__ velV,
                                                             const float4* __restrict__ acc,
-                                                            int* __restrict__ counters,
+                                                            int* __restrict__ blockCount,
                                                             const uint32_t* __restrict__ sortedKeys, int damp) {
     int s = blockIdx.x * kBlock + threadIdx.x;
     bool collided = false;
@@ -681,8 +738,7 @@ __global__ __launch_bounds__(kBlock) void k_full_bound_damp(DevParams P, float4*
         posM[s] = p;
         velV[s] = v;
     }
-    const unsigned long long m = __ballot(collided);
-    if (m && (threadIdx.x & 63) == 0) atomicAdd(&counters[SPH_CTR_COLLISIONS], __popcll(m));
+    block_count(collided, blockCount);
 }
 
 // CS_VelocityDamping (compute:492-509)

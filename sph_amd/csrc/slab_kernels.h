@@ -54,11 +54,29 @@ __device__ __forceinline__ SlabRecord make_record(const StateSet& st, int s) {
     r.id = st.origId[s];
     r.density = d.x;
     r.pressure = d.y;
-    r.phase = 0u;
+    r.phase = st.phase ? (uint32_t)st.phase[s] : 0u;
     return r;
 }
 
-__device__ __forceinline__ void store_record(const StateSet& st, int k, const SlabRecord& r) {
+// Records arrive with a phase id.  The packed neighbour records of the force kernel (PackedNbr) take
+// mass and viscosity from the phase table, which is only right if every record's own values ARE its
+// phase's row: any record that disagrees raises a sticky flag that switches that path off.
+struct PhaseCheck {
+    const sph_phase* table;   // null = no table set
+    int rows;
+    int* mismatch;
+};
+
+__device__ __forceinline__ void store_record(const StateSet& st, int k, const SlabRecord& r, const PhaseCheck& pc) {
+    if (st.phase) st.phase[k] = (uint8_t)(r.phase & 255u);
+    if (pc.table) {
+        bool ok = r.phase < (uint32_t)pc.rows;
+        if (ok) {
+            const sph_phase ph = pc.table[r.phase];
+            ok = ph.mass == r.posM.w && ph.viscosity == r.velV.w && ph.restDensity == r.accR.w;
+        }
+        if (!ok) *pc.mismatch = 1;
+    }
     st.posM[k] = r.posM;
     st.velV[k] = r.velV;
     st.acc[k] = make_float4(r.accR.x, r.accR.y, r.accR.z, 0.f);
@@ -87,30 +105,60 @@ __global__ __launch_bounds__(kBlock) void k_slab_pack(DevParams P, StateSet st, 
 }
 
 // Previously-owned particles that stay local (as owned or as ghost): current plane in [keepLo, keepHi).
+// Nearly every particle is kept, so a slot counter bumped once per wave would serialise ~n/64 atomics
+// on one address (measured: ~2 ns each, 0.3 ms at 2 M particles).  A workgroup handles kKeepItems x 256
+// particles and reserves its output range with ONE atomic.
+constexpr int kKeepItems = 8;
 __global__ __launch_bounds__(kBlock) void k_slab_keep(DevParams P, StateSet src, const uint32_t* __restrict__ sortedKeys,
                                                       int keepLo, int keepHi, StateSet dst, int capacity,
                                                       int* __restrict__ count) {
-    const int s = blockIdx.x * kBlock + threadIdx.x;
-    bool keep = false;
-    if (s < P.n && was_owned(P, sortedKeys, s)) {
-        const int g = global_plane(P, src.posM[s].x);
-        keep = g >= keepLo && g < keepHi;
+    __shared__ int waveTot[kBlock / 64];
+    __shared__ int blockBase;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int first = blockIdx.x * (kBlock * kKeepItems) + threadIdx.x;
+    unsigned long long kept[kKeepItems];
+    int mine = 0, tot = 0;
+#pragma unroll
+    for (int it = 0; it < kKeepItems; it++) {
+        const int s = first + it * kBlock;
+        bool keep = false;
+        if (s < P.n && was_owned(P, sortedKeys, s)) {
+            const int g = global_plane(P, src.posM[s].x);
+            keep = g >= keepLo && g < keepHi;
+        }
+        kept[it] = __ballot(keep);
+        mine |= (keep ? 1 : 0) << it;
+        tot += __popcll(kept[it]);
     }
-    const int k = wave_append(keep, count);
-    if (keep && k < capacity) {
-        dst.posM[k] = src.posM[s];
-        dst.velV[k] = src.velV[s];
-        dst.acc[k] = src.acc[s];
-        dst.rhoP[k] = src.rhoP[s];
-        dst.rho0[k] = src.rho0[s];
-        dst.origId[k] = src.origId[s];
+    if (lane == 0) waveTot[wave] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) blockBase = atomicAdd(count, (waveTot[0] + waveTot[1]) + (waveTot[2] + waveTot[3]));
+    __syncthreads();
+    int k = blockBase;
+    for (int w = 0; w < wave; w++) k += waveTot[w];
+#pragma unroll
+    for (int it = 0; it < kKeepItems; it++) {
+        if ((mine >> it) & 1) {
+            const int s = first + it * kBlock;
+            const int d = k + __popcll(kept[it] & ((1ull << lane) - 1ull));
+            if (d < capacity) {
+                dst.posM[d] = src.posM[s];
+                dst.velV[d] = src.velV[s];
+                dst.acc[d] = src.acc[s];
+                dst.rhoP[d] = src.rhoP[s];
+                dst.rho0[d] = src.rho0[s];
+                dst.origId[d] = src.origId[s];
+                if (src.phase) dst.phase[d] = src.phase[s];
+            }
+        }
+        k += __popcll(kept[it]);
     }
 }
 
 // Received records whose plane is in [keepLo, keepHi) join the local set.
 __global__ __launch_bounds__(kBlock) void k_slab_append(DevParams P, const SlabRecord* __restrict__ rec, int nrec,
                                                         int keepLo, int keepHi, StateSet dst, int capacity,
-                                                        int* __restrict__ count) {
+                                                        int* __restrict__ count, PhaseCheck pc) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     bool keep = false;
     SlabRecord r;
@@ -120,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void k_slab_append(DevParams P, const SlabR
         keep = g >= keepLo && g < keepHi;
     }
     const int k = wave_append(keep, count);
-    if (keep && k < capacity) store_record(dst, k, r);
+    if (keep && k < capacity) store_record(dst, k, r, pc);
 }
 
 // Export of the local set as records (owned only, or everything), compacted.
@@ -133,27 +181,10 @@ __global__ __launch_bounds__(kBlock) void k_slab_export(DevParams P, StateSet st
     if (take && k < cap) out[k] = make_record(st, s);
 }
 
-__global__ __launch_bounds__(kBlock) void k_slab_import(int n, const SlabRecord* __restrict__ rec, StateSet dst) {
+__global__ __launch_bounds__(kBlock) void k_slab_import(int n, const SlabRecord* __restrict__ rec, StateSet dst,
+                                                        PhaseCheck pc) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) store_record(dst, i, rec[i]);
-}
-
-// max over particles of |current search plane - plane binned at the last grid build|: the halo is
-// wide enough iff ghostPlanes >= 2 * (1 + this)   (see sph_amd/slab.py)
-__global__ __launch_bounds__(kBlock) void k_slab_plane_shift(DevParams P, const float4* __restrict__ posM,
-                                                             const uint32_t* __restrict__ sortedKeys,
-                                                             int* __restrict__ counters) {
-    const int s = blockIdx.x * kBlock + threadIdx.x;
-    int shift = 0;
-    if (s < P.n) {
-        int c = (int)floorf((posM[s].x - P.minBound[0]) / P.cellSize);
-        c = min(max(c, -2), P.rxg + 1);
-        const int binned = (int)(sortedKeys[s] % (uint32_t)P.rx) + P.xoff;
-        shift = abs(c - binned);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) shift = max(shift, __shfl_xor(shift, o));
-    if ((threadIdx.x & 63) == 0 && shift > 0) atomicMax(&counters[SPH_CTR_MAX_PLANE_SHIFT], shift);
+    if (i < n) store_record(dst, i, rec[i], pc);
 }
 
 }  // namespace sph

@@ -67,6 +67,7 @@ struct StateSet {
     float2*   rhoP;    // density, pressure
     float*    rho0;    // rest density
     uint32_t* origId;  // particle id living in this slot
+    uint8_t*  phase;   // slab mode: phase (spawn box) of the particle in this slot; elsewhere phases are kept by id
 };
 
 }  // namespace sph

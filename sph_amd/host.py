@@ -327,13 +327,14 @@ class SPH:
             # slab run: every rank walks the same global id sequence but only materialises the
             # boxes that can touch its planes, in bounded chunks (counter-based RNG, rule O9)
             e.alloc_particles(n)
+            e.set_phase_table(self._phase_rows())      # records are checked against it when they are uploaded
             index = 0
             for bi, sb in enumerate(self.spawnBoxes):
                 half_x = float(sb.spawnSize[0]) * 0.5
                 if e.box_may_matter(float(sb.SpawnCenter[0]) - half_x, float(sb.SpawnCenter[0]) + half_x):
                     for off in range(0, sb.particleCount, 1 << 20):
                         cnt = min(1 << 20, sb.particleCount - off)
-                        e.add_rows(index + off, self._spawn_rows(bi, sb, index, cnt, off))
+                        e.add_rows(index + off, self._spawn_rows(bi, sb, index, cnt, off), phase=bi)
                 index += sb.particleCount
             return
         init = np.zeros((n, abi.PARTICLE_FLOATS), dtype=np.float32)

@@ -76,9 +76,10 @@ class DevicePort:
         return self.send_l[:nl], self.send_r[:nr]
 
     def rebuild(self, keep_lo, keep_hi, from_left, from_right):
-        self.torch.cuda.synchronize(self.device)          # received data is complete
         pl = from_left.data_ptr() if from_left is not None and from_left.shape[0] else None
         pr = from_right.data_ptr() if from_right is not None and from_right.shape[0] else None
+        if pl is not None or pr is not None:
+            self.torch.cuda.synchronize(self.device)      # received data is complete
         nl = 0 if pl is None else from_left.shape[0]
         nr = 0 if pr is None else from_right.shape[0]
         return self.e.slab_rebuild(keep_lo, keep_hi, pl, nl, pr, nr)
@@ -94,13 +95,21 @@ class DevicePort:
 # communication: neighbour-to-neighbour send/recv of record tensors
 # ------------------------------------------------------------------------------------------------
 class NeighbourComm:
-    def __init__(self, rank: int, world: int, device, backend: Optional[str] = None):
+    """Neighbour-to-neighbour exchange of record tensors.  Count and payload buffers are allocated once;
+    per frame there is one host synchronisation (reading the two incoming counts)."""
+
+    def __init__(self, rank: int, world: int, device, backend: Optional[str] = None, msg_capacity: int = 0):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.rank, self.world, self.device = rank, world, device
         self.backend = backend or dist.get_backend()
         self.stage_cpu = self.backend == "gloo"
+        dev = self._dev()
+        self.cnt_send = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.cnt_recv = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.cap = int(msg_capacity)
+        self.buf = [torch.empty((self.cap, REC), dtype=torch.uint8, device=dev) for _ in range(2)] if self.cap else None
 
     def _dev(self):
         return self.torch.device("cpu") if self.stage_cpu else self.device
@@ -115,38 +124,41 @@ class NeighbourComm:
             for w in self.dist.batch_isend_irecv(ops):
                 w.wait()
 
+    def _recv_buffer(self, side, n):
+        if self.buf is not None and n <= self.cap:
+            return self.buf[side][:n]
+        return self.torch.empty((n, REC), dtype=self.torch.uint8, device=self._dev())
+
     def exchange(self, to_left, to_right):
         """Send to_left to rank-1 and to_right to rank+1; returns (from_left, from_right)."""
         torch = self.torch
         left = self.rank - 1 if self.rank > 0 else None
         right = self.rank + 1 if self.rank < self.world - 1 else None
-        dev = self._dev()
-        # 1) counts
-        cs_l = torch.tensor([to_left.shape[0]], dtype=torch.int64, device=dev)
-        cs_r = torch.tensor([to_right.shape[0]], dtype=torch.int64, device=dev)
-        cr_l = torch.zeros(1, dtype=torch.int64, device=dev)
-        cr_r = torch.zeros(1, dtype=torch.int64, device=dev)
+        if left is None and right is None:
+            return None, None
+        # 1) counts (two preallocated int64 pairs; fill_ is asynchronous, tolist() is the one sync)
+        self.cnt_send[0:1].fill_(int(to_left.shape[0]))
+        self.cnt_send[1:2].fill_(int(to_right.shape[0]))
+        self.cnt_recv.zero_()
         sends, recvs = [], []
         if left is not None:
-            sends.append((cs_l, left)); recvs.append((cr_l, left))
+            sends.append((self.cnt_send[0:1], left)); recvs.append((self.cnt_recv[0:1], left))
         if right is not None:
-            sends.append((cs_r, right)); recvs.append((cr_r, right))
+            sends.append((self.cnt_send[1:2], right)); recvs.append((self.cnt_recv[1:2], right))
         self._xfer(sends, recvs)
-        n_from_l, n_from_r = int(cr_l.item()), int(cr_r.item())
+        n_from_l, n_from_r = (int(v) for v in self.cnt_recv.tolist())
         # 2) payload
-        buf_l = torch.empty((n_from_l, REC), dtype=torch.uint8, device=dev)
-        buf_r = torch.empty((n_from_r, REC), dtype=torch.uint8, device=dev)
-        sl = to_left.to(dev).contiguous() if left is not None else None
-        sr = to_right.to(dev).contiguous() if right is not None else None
+        dev = self._dev()
+        buf_l, buf_r = self._recv_buffer(0, n_from_l), self._recv_buffer(1, n_from_r)
         sends, recvs = [], []
         if left is not None:
-            if sl.shape[0]:
-                sends.append((sl, left))
+            if to_left.shape[0]:
+                sends.append((to_left.to(dev).contiguous(), left))
             if n_from_l:
                 recvs.append((buf_l, left))
         if right is not None:
-            if sr.shape[0]:
-                sends.append((sr, right))
+            if to_right.shape[0]:
+                sends.append((to_right.to(dev).contiguous(), right))
             if n_from_r:
                 recvs.append((buf_r, right))
         self._xfer(sends, recvs)
@@ -210,19 +222,24 @@ class SlabEngine:
         lo, hi = self._planes([lo_x, hi_x])
         return hi >= self.own[0] - 1 and lo <= self.own[1]
 
-    def add_rows(self, first_id, rows):
-        """rows: (k, 18) float32 AoS rows of global ids first_id .. first_id+k-1; only those in the
-        owned planes are kept (ghosts arrive with the first exchange)."""
+    def add_rows(self, first_id, rows, phase=0):
+        """rows: (k, 18) float32 AoS rows of global ids first_id .. first_id+k-1, all of spawn box
+        `phase`; only those in the owned planes are kept (ghosts arrive with the first exchange)."""
         plane = self._planes(rows[:, 0])
         m = (plane >= self.own[0]) & (plane < self.own[1])
         ids = (int(first_id) + np.flatnonzero(m)).astype(np.uint32)
-        self._rows.append(abi.records_from_aos(rows[m], ids))
+        self._rows.append(abi.records_from_aos(rows[m], ids, phase))
 
     def upload_particles(self, aos):
         self.add_rows(0, np.asarray(aos, dtype=np.float32).reshape(-1, abi.PARTICLE_FLOATS))
 
     def set_phase_table(self, phases):
-        pass            # slab records carry restDensity / viscosity / mass themselves
+        # slab records carry restDensity / viscosity / mass themselves; the table only tells the engine
+        # that mass and viscosity are per-phase constants (packed neighbour records of the force kernel).
+        # Live edits of a spawn box are not propagated to the particles in slab mode.
+        self._phases = phases
+        if self._rows is None and hasattr(self.e, "set_phase_table"):
+            self.e.set_phase_table(phases)
 
     def set_phase_ids(self, ids):
         pass
@@ -258,6 +275,8 @@ class SlabEngine:
         share = max(self.n_global // self.world, owned.shape[0], 1024)
         capacity = int(share * self.capacity_factor) + 4096
         self.port.configure(rx, self.keep[0], self.keep[1] - self.keep[0], ry, rz, cap, x0, x1, capacity)
+        if getattr(self, "_phases", None) and hasattr(self.e, "set_phase_table"):
+            self.e.set_phase_table(self._phases)       # before the upload: records are checked against it
         self.port.upload_owned(owned)
         self.n = owned.shape[0]
 
@@ -271,9 +290,9 @@ class SlabEngine:
         rx = self.grid[0]
         left_below = x0 + self.ghost if self.rank > 0 else 0
         right_from = x1 - self.ghost if self.rank < self.world - 1 else rx
-        if self.frames > 0:
+        if self.frames > 0 and self.world > 1:
             shift = self.e.read_counter(abi.CTR_MAX_PLANE_SHIFT)
-            if 2 * (1 + shift) > self.ghost and self.world > 1:
+            if 2 * (1 + shift) > self.ghost:
                 self.halo_violations += 1
         to_l, to_r = self.port.pack(left_below, right_from)
         from_l, from_r = self.comm.exchange(to_l, to_r)
@@ -346,7 +365,8 @@ def bench_main(args, rank, local_rank, world):
     per_gpu = args.particles or 8388608
     eng = abi.Engine(local_rank)
     port = DevicePort(eng, local_rank, msg_capacity=max(per_gpu // 4, 65536))
-    comm = NeighbourComm(rank, world, torch.device("cuda", local_rank), backend=backend)
+    comm = NeighbourComm(rank, world, torch.device("cuda", local_rank), backend=backend,
+                         msg_capacity=max(per_gpu // 4, 65536))
     se = SlabEngine(port, comm, rank, world, ghost_planes=8)
     sc = scenes.config5(se, gpus=world, per_gpu=per_gpu)
     sc.sph.use_step_frame = True

@@ -15,7 +15,7 @@ from tests.test_slab_gloo import _free_port, small_tank
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, frames, out_dir, n, ghost):
+def _worker(rank, world, port, frames, out_dir, n, ghost, drop_phases):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -23,6 +23,12 @@ def _worker(rank, world, port, frames, out_dir, n, ghost):
     dport = slab.DevicePort(eng, 0, msg_capacity=n)
     comm = slab.NeighbourComm(rank, world, torch.device("cuda", 0), backend="gloo")
     se = slab.SlabEngine(dport, comm, rank, world, ghost_planes=ghost)
+    if drop_phases:
+        # records arrive without their spawn-box index: the second box's mass / viscosity / rest density
+        # then disagree with row 0 of the phase table, and the engine has to notice (PhaseCheck) and
+        # keep gathering mass and viscosity per particle
+        add = se.add_rows
+        se.add_rows = lambda first_id, rows, phase=0: add(first_id, rows, 0)
     sc = small_tank(se, n=n)
     sc.sph.use_step_frame = True
     sc.start()
@@ -38,8 +44,9 @@ def _worker(rank, world, port, frames, out_dir, n, ghost):
 
 # (6, 4): six slabs of 8 planes with 4 ghost planes; the outer slabs hold NO particle at first
 # (an empty slab must step like any other) and fill up as the fluid spreads
-@pytest.mark.parametrize("world,ghost", [(1, 8), (2, 8), (3, 8), (6, 4)])
-def test_slabs_equal_single_engine_bitwise(tmp_path, world, ghost):
+@pytest.mark.parametrize("world,ghost,drop_phases", [(1, 8, False), (2, 8, False), (3, 8, False), (6, 4, False),
+                                                     (2, 8, True)])
+def test_slabs_equal_single_engine_bitwise(tmp_path, world, ghost, drop_phases):
     frames, n = 8, 3000
     eng = abi.Engine(0)
     sc = small_tank(eng, n=n)
@@ -49,7 +56,7 @@ def test_slabs_equal_single_engine_bitwise(tmp_path, world, ghost):
     eng.destroy()
     n = want.shape[0]
 
-    mp.spawn(_worker, args=(world, _free_port(), frames, str(tmp_path), n, ghost), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), frames, str(tmp_path), n, ghost, drop_phases), nprocs=world, join=True)
     recs = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)])
     meta = np.load(tmp_path / "meta0.npy")
     assert meta[:-1].tolist() == [n] * frames, "particles not conserved across slabs"
