@@ -83,6 +83,7 @@ struct sph_ctx {
     int* blockInts = nullptr;         // one int per workgroup: collision counts of the boundary kernels; slab
                                       // mode: plane shifts of the density kernel (capacity / 256 + 1 ints)
     int* phaseMismatch = nullptr;     // device flag: some slab record's statics are not its phase's row (PhaseCheck)
+    int cachedShift = -1;             // SPH_CTR_MAX_PLANE_SHIFT as read along with sph_slab_pack's counts (-1 = not cached)
     bool slabPackedOff = false;       // the phase table changed after the records were uploaded
     SlabRecord* recStage = nullptr;   // device staging for slab upload / download
     size_t recStageCap = 0;
@@ -304,6 +305,7 @@ int clearGrid(sph_ctx* c, bool resetBuildCounters = false) {
     CHECK_LAUNCH(c);
     c->gridValid = false;
     c->maskValid = false;
+    c->cachedShift = -1;
     return SPH_OK;
 }
 
@@ -756,6 +758,7 @@ int sph_reset_counter(sph_ctx* c, int which) {
     if (which < 0 || which >= SPH_CTR_COUNT) return fail(c, SPH_E_INVALID, "bad counter %d", which);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemsetAsync(c->counters + which, 0, sizeof(int), c->stream));
+    if (which == SPH_CTR_MAX_PLANE_SHIFT) c->cachedShift = -1;
     return SPH_OK;
 }
 
@@ -763,6 +766,7 @@ int sph_read_counter(sph_ctx* c, int which, int* value) {
     if (!c) return SPH_E_INVALID;
     if (which < 0 || which >= SPH_CTR_COUNT || !value) return fail(c, SPH_E_INVALID, "bad counter %d", which);
     HIP_TRY(c, hipSetDevice(c->device));
+    if (which == SPH_CTR_MAX_PLANE_SHIFT && c->cachedShift >= 0) { *value = c->cachedShift; return SPH_OK; }
     if (int rcRead = readInts(c, c->counters + which, 1, value)) return rcRead;
     return SPH_OK;
 }
@@ -994,12 +998,16 @@ int sph_slab_pack(sph_ctx* c, int left_below, int right_from, void* dev_left, in
     *n_left = *n_right = 0;
     if (c->n == 0) return SPH_OK;
     HIP_TRY(c, hipMemsetAsync(c->slabCounts, 0, 4 * sizeof(int), c->stream));
-    hipLaunchKernelGGL(k_slab_pack, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->dp, curSet(c),
+    hipLaunchKernelGGL(k_slab_pack, dim3((c->n + kBlock * kKeepItems - 1) / (kBlock * kKeepItems)), dim3(kBlock), 0, c->stream, c->dp, curSet(c),
                        c->gridValid ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr, left_below, right_from,
                        (SlabRecord*)dev_left, cap_left, (SlabRecord*)dev_right, cap_right, c->slabCounts);
     CHECK_LAUNCH(c);
+    // the two message sizes and -- same synchronisation -- the frame's plane shift, which the driver asks for next
     int cnt[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(c->hostInts + 8, c->counters + SPH_CTR_MAX_PLANE_SHIFT, sizeof(int), hipMemcpyDeviceToHost,
+                              c->stream));
     if (int rcRead = readInts(c, c->slabCounts, 2, cnt)) return rcRead;
+    c->cachedShift = c->hostInts[8];
     *n_left = cnt[0];
     *n_right = cnt[1];
     if (cnt[0] > cap_left || cnt[1] > cap_right)

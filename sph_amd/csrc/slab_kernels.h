@@ -87,28 +87,64 @@ __device__ __forceinline__ void store_record(const StateSet& st, int k, const Sl
 
 // Messages to the slab neighbours: previously-owned particles whose CURRENT plane is below
 // `leftBelow` (-> left message) or at/above `rightFrom` (-> right message).  counts[0..1].
+// A workgroup handles kKeepItems x 256 particles and reserves its part of each message with one
+// atomic (the band particles are the two ends of every cell row, so most waves hold a few; one
+// atomic per wave would again serialise on the two counters).
+constexpr int kKeepItems = 8;
 __global__ __launch_bounds__(kBlock) void k_slab_pack(DevParams P, StateSet st, const uint32_t* __restrict__ sortedKeys,
                                                       int leftBelow, int rightFrom, SlabRecord* __restrict__ left,
                                                       int capLeft, SlabRecord* __restrict__ right, int capRight,
                                                       int* __restrict__ counts) {
-    const int s = blockIdx.x * kBlock + threadIdx.x;
-    bool toL = false, toR = false;
-    if (s < P.n && was_owned(P, sortedKeys, s)) {
-        const int g = global_plane(P, st.posM[s].x);
-        toL = g < leftBelow;
-        toR = g >= rightFrom;
+    __shared__ int waveTot[2][kBlock / 64];
+    __shared__ int blockBase[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int first = blockIdx.x * (kBlock * kKeepItems) + threadIdx.x;
+    unsigned long long mL[kKeepItems], mR[kKeepItems];
+    int totL = 0, totR = 0;
+#pragma unroll
+    for (int it = 0; it < kKeepItems; it++) {
+        const int s = first + it * kBlock;
+        bool toL = false, toR = false;
+        if (s < P.n && was_owned(P, sortedKeys, s)) {
+            const int g = global_plane(P, st.posM[s].x);
+            toL = g < leftBelow;
+            toR = g >= rightFrom;
+        }
+        mL[it] = __ballot(toL);
+        mR[it] = __ballot(toR);
+        totL += __popcll(mL[it]);
+        totR += __popcll(mR[it]);
     }
-    const int il = wave_append(toL, &counts[0]);
-    const int ir = wave_append(toR, &counts[1]);
-    if (toL && il < capLeft) left[il] = make_record(st, s);
-    if (toR && ir < capRight) right[ir] = make_record(st, s);
+    if (lane == 0) { waveTot[0][wave] = totL; waveTot[1][wave] = totR; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int t = (waveTot[threadIdx.x][0] + waveTot[threadIdx.x][1]) + (waveTot[threadIdx.x][2] + waveTot[threadIdx.x][3]);
+        blockBase[threadIdx.x] = t ? atomicAdd(&counts[threadIdx.x], t) : 0;
+    }
+    __syncthreads();
+    int kL = blockBase[0], kR = blockBase[1];
+    for (int w = 0; w < wave; w++) { kL += waveTot[0][w]; kR += waveTot[1][w]; }
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int it = 0; it < kKeepItems; it++) {
+        const int s = first + it * kBlock;
+        if ((mL[it] >> lane) & 1ull) {
+            const int d = kL + __popcll(mL[it] & below);
+            if (d < capLeft) left[d] = make_record(st, s);
+        }
+        if ((mR[it] >> lane) & 1ull) {
+            const int d = kR + __popcll(mR[it] & below);
+            if (d < capRight) right[d] = make_record(st, s);
+        }
+        kL += __popcll(mL[it]);
+        kR += __popcll(mR[it]);
+    }
 }
 
 // Previously-owned particles that stay local (as owned or as ghost): current plane in [keepLo, keepHi).
 // Nearly every particle is kept, so a slot counter bumped once per wave would serialise ~n/64 atomics
 // on one address (measured: ~2 ns each, 0.3 ms at 2 M particles).  A workgroup handles kKeepItems x 256
 // particles and reserves its output range with ONE atomic.
-constexpr int kKeepItems = 8;
 __global__ __launch_bounds__(kBlock) void k_slab_keep(DevParams P, StateSet src, const uint32_t* __restrict__ sortedKeys,
                                                       int keepLo, int keepHi, StateSet dst, int capacity,
                                                       int* __restrict__ count) {

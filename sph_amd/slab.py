@@ -290,11 +290,11 @@ class SlabEngine:
         rx = self.grid[0]
         left_below = x0 + self.ghost if self.rank > 0 else 0
         right_from = x1 - self.ghost if self.rank < self.world - 1 else rx
+        to_l, to_r = self.port.pack(left_below, right_from)
         if self.frames > 0 and self.world > 1:
-            shift = self.e.read_counter(abi.CTR_MAX_PLANE_SHIFT)
+            shift = self.e.read_counter(abi.CTR_MAX_PLANE_SHIFT)     # came back with pack's counts: no extra sync
             if 2 * (1 + shift) > self.ghost:
                 self.halo_violations += 1
-        to_l, to_r = self.port.pack(left_below, right_from)
         from_l, from_r = self.comm.exchange(to_l, to_r)
         self.n = self.port.rebuild(self.keep[0], self.keep[1], from_l, from_r)
         self.e.n = self.n
