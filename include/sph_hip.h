@@ -231,7 +231,12 @@ int  sph_slab_download(sph_ctx* ctx, sph_slab_record* records, int max_records, 
 int  sph_slab_pack(sph_ctx* ctx, int left_below, int right_from, void* dev_left, int cap_left,
                    void* dev_right, int cap_right, int* n_left, int* n_right);
 /* New local set = owned particles whose current global plane is in [keep_lo, keep_hi) + the received
- * records (DEVICE buffers) in that plane range.  Last frame's ghosts are dropped.  Synchronises. */
+ * records (DEVICE buffers) in that plane range; last frame's ghosts are dropped.  The call only appends
+ * the records behind the current particles and arms a filter: the NEXT grid build (CS_BuildGrid
+ * dispatch or sph_step_frame), which must follow before anything else reads the particles, drops
+ * what does not belong while it sorts -- no separate compaction pass.  *n_local is therefore an upper
+ * bound (what CS_ClearGrid / CS_BuildGrid dispatches must pass as count); sph_particle_count gives
+ * the exact number after the build.  Does not synchronise. */
 int  sph_slab_rebuild(sph_ctx* ctx, int keep_lo, int keep_hi, const void* dev_from_left, int n_from_left,
                       const void* dev_from_right, int n_from_right, int* n_local);
 /* Current local particle count (owned + ghosts). */

@@ -35,14 +35,36 @@ __device__ __forceinline__ int3 cell_unclamped(const DevParams& P, float x, floa
 // Kernels index the table through cellCum = T - 1 (cellCum[c] = #particles with cell < c): the bin
 // of cell c is [cellCum[c], cellCum[c+1]) and any run of consecutive cells [c0, c1] is the single
 // slot range [cellCum[c0], cellCum[c1+1]) -- what the 3-cells-per-row search reads with two loads.
+// Slab mode: which of the source slots take part in this build.  Slots below nOld held particles at
+// the last build: those that were OWNED then (their ghosts are stale copies) and whose plane is now in
+// [keepLo, keepHi) stay; slots from nOld on are records just received from the slab neighbours and
+// stay if their plane is in range.  Everything else gets no key, is not counted and is not placed:
+// the counting sort itself is the compaction, no separate copy of the survivors.
+struct SlabFilter {
+    int active, keepLo, keepHi, nOld;
+    const uint32_t* oldKeys;         // keys of the last build (null before the first one: everything was owned)
+};
+
 __global__ __launch_bounds__(kBlock) void k_hash_count(DevParams P, const float4* __restrict__ posM,
                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ arrival,
-                                                       int* __restrict__ T, int* __restrict__ counters) {
+                                                       int* __restrict__ T, int* __restrict__ counters, SlabFilter F) {
     int s = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     bool oog = false;
     uint32_t key = 0xFFFFFFFFu;                          // lanes past the end: a run of their own, no atomic
-    if (s < P.n) {
+    bool take = s < P.n;
+    if (take && F.active) {
+        if (s < F.nOld && F.oldKeys) {
+            const int plane = (int)(F.oldKeys[s] % (uint32_t)P.rx);
+            take = plane >= P.ownLo && plane < P.ownHi;
+        }
+        if (take) {
+            const int g = min(max((int)floorf((posM[s].x - P.minBound[0]) / P.cellSize), 0), P.rxg - 1);
+            take = g >= F.keepLo && g < F.keepHi;
+        }
+        if (!take) keys[s] = 0xFFFFFFFFu;
+    }
+    if (take) {
         float4 p = posM[s];
         int3 c = cell_unclamped(P, p.x, p.y, p.z);
         oog = c.x < 0 || c.x >= P.rxg || c.y < 0 || c.y >= P.ry || c.z < 0 || c.z >= P.rz;
@@ -159,6 +181,7 @@ __global__ __launch_bounds__(kBlock) void k_place(int n, const uint32_t* __restr
     int s = blockIdx.x * kBlock + threadIdx.x;
     if (s >= n) return;
     const uint32_t key = keys[s];
+    if (key == 0xFFFFFFFFu) return;                      // slab mode: not part of this build (SlabFilter)
     const int t = cellCum[key] + (int)arrival[s];
     sortedKeys[t] = key;
     perm[t] = (uint32_t)s;

@@ -83,6 +83,7 @@ struct sph_ctx {
     int* blockInts = nullptr;         // one int per workgroup: collision counts of the boundary kernels; slab
                                       // mode: plane shifts of the density kernel (capacity / 256 + 1 ints)
     int* phaseMismatch = nullptr;     // device flag: some slab record's statics are not its phase's row (PhaseCheck)
+    SlabFilter filter{};              // set by sph_slab_rebuild, consumed by the next grid build
     int cachedShift = -1;             // SPH_CTR_MAX_PLANE_SHIFT as read along with sph_slab_pack's counts (-1 = not cached)
     bool slabPackedOff = false;       // the phase table changed after the records were uploaded
     SlabRecord* recStage = nullptr;   // device staging for slab upload / download
@@ -316,6 +317,8 @@ int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
     const int nb = blocksFor(n);
     int rc = clearGrid(c, true);
     if (rc) return rc;
+    const SlabFilter filter = c->filter;
+    c->filter.active = 0;
     if (n == 0) {   // an empty slab: the zeroed table is its grid
         c->gridValid = true;
         return SPH_OK;
@@ -324,7 +327,7 @@ int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
     // keys[0] = cell per old slot, vals[0] = arrival number; keys[1] / vals[1] / sid = key, source slot
     // and id per bucket slot
     hipLaunchKernelGGL(k_hash_count, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, src.posM, c->keys[0], c->vals[0],
-                       c->cumT, c->counters);
+                       c->cumT, c->counters, filter);
     CHECK_LAUNCH(c);
     {   // counts -> cumulative cell table
         const long long cells4 = (c->tableCells + 3) / 4;
@@ -337,14 +340,23 @@ int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
     uint32_t* perm = c->vals[1];
     hipLaunchKernelGGL(k_place, dim3(nb), dim3(kBlock), 0, c->stream, n, c->keys[0], c->vals[0], src.origId,
                        c->cellCum, c->sortedKeys, perm, c->sid);
+    int nNew = n;
+    if (filter.active) {
+        // the survivors are what the table counted: one read, the only synchronisation of a slab rebuild
+        if (int rcRead = readInts(c, c->cellCum + c->tableCells, 1, &nNew)) return rcRead;
+        c->n = nNew;
+        c->dp.n = nNew;
+        if (nNew == 0) { c->cur = 1 - c->cur; c->velCur = 1 - c->velCur; c->gridValid = true; return SPH_OK; }
+    }
+    const int nbNew = blocksFor(nNew);
     StateSet dst = c->set[1 - c->cur];
     // velocities of the new order go to the set that does NOT hold the current ones
     dst.velV = c->set[1 - c->velCur].velV;
     if (fuseHalfStep)   // sph_step_frame: rank + reorder + first CS_VvHalfStep in one pass
-        hipLaunchKernelGGL(k_rank_move<true>, dim3(nb), dim3(kBlock), 0, c->stream, c->sortedKeys, perm, c->sid, n, c->cap,
+        hipLaunchKernelGGL(k_rank_move<true>, dim3(nbNew), dim3(kBlock), 0, c->stream, c->sortedKeys, perm, c->sid, nNew, c->cap,
                            c->dp.dt, c->cellCum, src, dst, c->counters);
     else
-        hipLaunchKernelGGL(k_rank_move<false>, dim3(nb), dim3(kBlock), 0, c->stream, c->sortedKeys, perm, c->sid, n, c->cap,
+        hipLaunchKernelGGL(k_rank_move<false>, dim3(nbNew), dim3(kBlock), 0, c->stream, c->sortedKeys, perm, c->sid, nNew, c->cap,
                            c->dp.dt, c->cellCum, src, dst, c->counters);
     CHECK_LAUNCH(c);
     c->cur = 1 - c->cur;
@@ -1024,31 +1036,26 @@ int sph_slab_rebuild(sph_ctx* c, int keep_lo, int keep_hi, const void* dev_from_
     HIP_TRY(c, hipSetDevice(c->device));
     deriveParams(c);
     c->dp.n = c->n;
-    StateSet src = curSet(c);
-    StateSet dst = c->set[1 - c->cur];
-    dst.velV = c->set[1 - c->velCur].velV;
-    HIP_TRY(c, hipMemsetAsync(c->slabCounts, 0, 4 * sizeof(int), c->stream));
-    if (c->n > 0)
-        hipLaunchKernelGGL(k_slab_keep, dim3((c->n + kBlock * kKeepItems - 1) / (kBlock * kKeepItems)), dim3(kBlock), 0, c->stream, c->dp, src,
-                           c->gridValid ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr, keep_lo, keep_hi, dst,
-                           c->capacity, c->slabCounts);
+    // No copy of the survivors: the received records are appended behind the current particles and the
+    // next grid build (which follows in the same frame) drops what does not belong -- stale ghosts,
+    // emigrants, records outside [keep_lo, keep_hi) -- while it sorts (SlabFilter).
+    const int nOld = c->n;
+    if ((long long)nOld + n_from_left + n_from_right > c->capacity)
+        return fail(c, SPH_E_NOMEM, "slab population %d + %d + %d received exceeds the reserved capacity %d", nOld,
+                    n_from_left, n_from_right, c->capacity);
+    StateSet cur = curSet(c);
     if (n_from_left > 0)
-        hipLaunchKernelGGL(k_slab_append, dim3(blocksFor(n_from_left)), dim3(kBlock), 0, c->stream, c->dp,
-                           (const SlabRecord*)dev_from_left, n_from_left, keep_lo, keep_hi, dst, c->capacity, c->slabCounts,
-                           phaseCheck(c));
+        hipLaunchKernelGGL(k_slab_append_at, dim3(blocksFor(n_from_left)), dim3(kBlock), 0, c->stream,
+                           (const SlabRecord*)dev_from_left, n_from_left, cur, nOld, phaseCheck(c));
     if (n_from_right > 0)
-        hipLaunchKernelGGL(k_slab_append, dim3(blocksFor(n_from_right)), dim3(kBlock), 0, c->stream, c->dp,
-                           (const SlabRecord*)dev_from_right, n_from_right, keep_lo, keep_hi, dst, c->capacity,
-                           c->slabCounts, phaseCheck(c));
+        hipLaunchKernelGGL(k_slab_append_at, dim3(blocksFor(n_from_right)), dim3(kBlock), 0, c->stream,
+                           (const SlabRecord*)dev_from_right, n_from_right, cur, nOld + n_from_left, phaseCheck(c));
     CHECK_LAUNCH(c);
-    int cnt = 0;
-    if (int rcRead = readInts(c, c->slabCounts, 1, &cnt)) return rcRead;
-    if (cnt > c->capacity) return fail(c, SPH_E_NOMEM, "slab population %d exceeds the reserved capacity %d", cnt, c->capacity);
-    c->cur = 1 - c->cur;
-    c->velCur = 1 - c->velCur;
-    c->n = cnt;
+    c->filter = SlabFilter{1, keep_lo, keep_hi, nOld,
+                           c->gridValid ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr};
+    c->n = nOld + n_from_left + n_from_right;
     c->gridValid = false; c->maskValid = false;
-    *n_local = cnt;
+    *n_local = c->n;       // upper bound until the grid build; sph_particle_count afterwards
     return SPH_OK;
 }
 

@@ -141,70 +141,12 @@ __global__ __launch_bounds__(kBlock) void k_slab_pack(DevParams P, StateSet st, 
     }
 }
 
-// Previously-owned particles that stay local (as owned or as ghost): current plane in [keepLo, keepHi).
-// Nearly every particle is kept, so a slot counter bumped once per wave would serialise ~n/64 atomics
-// on one address (measured: ~2 ns each, 0.3 ms at 2 M particles).  A workgroup handles kKeepItems x 256
-// particles and reserves its output range with ONE atomic.
-__global__ __launch_bounds__(kBlock) void k_slab_keep(DevParams P, StateSet src, const uint32_t* __restrict__ sortedKeys,
-                                                      int keepLo, int keepHi, StateSet dst, int capacity,
-                                                      int* __restrict__ count) {
-    __shared__ int waveTot[kBlock / 64];
-    __shared__ int blockBase;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int first = blockIdx.x * (kBlock * kKeepItems) + threadIdx.x;
-    unsigned long long kept[kKeepItems];
-    int mine = 0, tot = 0;
-#pragma unroll
-    for (int it = 0; it < kKeepItems; it++) {
-        const int s = first + it * kBlock;
-        bool keep = false;
-        if (s < P.n && was_owned(P, sortedKeys, s)) {
-            const int g = global_plane(P, src.posM[s].x);
-            keep = g >= keepLo && g < keepHi;
-        }
-        kept[it] = __ballot(keep);
-        mine |= (keep ? 1 : 0) << it;
-        tot += __popcll(kept[it]);
-    }
-    if (lane == 0) waveTot[wave] = tot;
-    __syncthreads();
-    if (threadIdx.x == 0) blockBase = atomicAdd(count, (waveTot[0] + waveTot[1]) + (waveTot[2] + waveTot[3]));
-    __syncthreads();
-    int k = blockBase;
-    for (int w = 0; w < wave; w++) k += waveTot[w];
-#pragma unroll
-    for (int it = 0; it < kKeepItems; it++) {
-        if ((mine >> it) & 1) {
-            const int s = first + it * kBlock;
-            const int d = k + __popcll(kept[it] & ((1ull << lane) - 1ull));
-            if (d < capacity) {
-                dst.posM[d] = src.posM[s];
-                dst.velV[d] = src.velV[s];
-                dst.acc[d] = src.acc[s];
-                dst.rhoP[d] = src.rhoP[s];
-                dst.rho0[d] = src.rho0[s];
-                dst.origId[d] = src.origId[s];
-                if (src.phase) dst.phase[d] = src.phase[s];
-            }
-        }
-        k += __popcll(kept[it]);
-    }
-}
-
-// Received records whose plane is in [keepLo, keepHi) join the local set.
-__global__ __launch_bounds__(kBlock) void k_slab_append(DevParams P, const SlabRecord* __restrict__ rec, int nrec,
-                                                        int keepLo, int keepHi, StateSet dst, int capacity,
-                                                        int* __restrict__ count, PhaseCheck pc) {
+// Received records become source slots base .. base+nrec-1 of the current set; which of them (and of
+// the old slots) survive is decided by the next grid build (SlabFilter in k_hash_count).
+__global__ __launch_bounds__(kBlock) void k_slab_append_at(const SlabRecord* __restrict__ rec, int nrec, StateSet dst,
+                                                           int base, PhaseCheck pc) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    bool keep = false;
-    SlabRecord r;
-    if (i < nrec) {
-        r = rec[i];
-        const int g = global_plane(P, r.posM.x);
-        keep = g >= keepLo && g < keepHi;
-    }
-    const int k = wave_append(keep, count);
-    if (keep && k < capacity) store_record(dst, k, r, pc);
+    if (i < nrec) store_record(dst, base + i, rec[i], pc);
 }
 
 // Export of the local set as records (owned only, or everything), compacted.

@@ -300,11 +300,19 @@ class SlabEngine:
         self.e.n = self.n
         self.exchange_s += time.perf_counter() - t0
 
+    def _refresh_count(self):
+        """The rebuild only appends; the grid build that follows drops what does not belong to the slab,
+        so the local count is known after it."""
+        if hasattr(self.port, "local_count"):
+            self.n = self.port.local_count()
+            self.e.n = self.n
+
     def step_frame(self, sub_steps, time_step):
         if sub_steps != 1 and self.world > 1:
             raise NotImplementedError("slab mode supports subSteps == 1 (no per-sub-step ghost refresh yet)")
         self.exchange()
         self.e.step_frame(sub_steps, time_step)
+        self._refresh_count()
         self.frames += 1
 
     def dispatch(self, kernel_id, count):
@@ -313,6 +321,8 @@ class SlabEngine:
             self.e.dispatch(kernel_id, self.e.cells)
         else:
             self.e.dispatch(kernel_id, self.n)
+            if kernel_id == abi.K_BUILD_GRID:
+                self._refresh_count()
         if kernel_id == abi.K_VELOCITY_DAMPING:
             self.frames += 1
 
