@@ -74,6 +74,7 @@ struct sph_ctx {
     int lastForceVariant = -1;
 
     int* counters = nullptr;          // SPH_CTR_COUNT ints on the device
+    bool collisionsResetPending = false;   // sph_reset_counter(COLLISIONS) seen; applied by the next k_sum_into
     int* hostInts = nullptr;          // 16 pinned ints: landing zone of the small device -> host reads
 
     // slab decomposition (multi-GPU)
@@ -444,7 +445,8 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false)
                                    c->blockInts, c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr,
                                    lastSub ? 1 : 0);
                 hipLaunchKernelGGL(k_sum_into, dim3(1), dim3(kBlock), 0, c->stream, c->blockInts, nb,
-                                   c->counters + SPH_CTR_COLLISIONS);
+                                   c->counters + SPH_CTR_COLLISIONS, c->collisionsResetPending ? 1 : 0);
+                c->collisionsResetPending = false;
                 break;
             }
             hipLaunchKernelGGL(k_full_step, dim3(nb), dim3(kBlock), 0, c->stream, n, c->dp.dt, s.velV, s.acc);
@@ -454,7 +456,8 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false)
             hipLaunchKernelGGL(k_bound_obs, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, c->blockInts,
                                c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr);
             hipLaunchKernelGGL(k_sum_into, dim3(1), dim3(kBlock), 0, c->stream, c->blockInts, nb,
-                               c->counters + SPH_CTR_COLLISIONS);
+                               c->counters + SPH_CTR_COLLISIONS, c->collisionsResetPending ? 1 : 0);
+                c->collisionsResetPending = false;
             break;
         case SPH_K_VELOCITY_DAMPING:
             hipLaunchKernelGGL(k_velocity_damping, dim3(nb), dim3(kBlock), 0, c->stream, n, s.velV);
@@ -769,6 +772,10 @@ int sph_reset_counter(sph_ctx* c, int which) {
     if (!c) return SPH_E_INVALID;
     if (which < 0 || which >= SPH_CTR_COUNT) return fail(c, SPH_E_INVALID, "bad counter %d", which);
     HIP_TRY(c, hipSetDevice(c->device));
+    if (which == SPH_CTR_COLLISIONS) {   // SPH.cs:190 does this every frame: no launch, the next boundary pass overwrites
+        c->collisionsResetPending = true;
+        return SPH_OK;
+    }
     HIP_TRY(c, hipMemsetAsync(c->counters + which, 0, sizeof(int), c->stream));
     if (which == SPH_CTR_MAX_PLANE_SHIFT) c->cachedShift = -1;
     return SPH_OK;
@@ -779,6 +786,7 @@ int sph_read_counter(sph_ctx* c, int which, int* value) {
     if (which < 0 || which >= SPH_CTR_COUNT || !value) return fail(c, SPH_E_INVALID, "bad counter %d", which);
     HIP_TRY(c, hipSetDevice(c->device));
     if (which == SPH_CTR_MAX_PLANE_SHIFT && c->cachedShift >= 0) { *value = c->cachedShift; return SPH_OK; }
+    if (which == SPH_CTR_COLLISIONS && c->collisionsResetPending) { *value = 0; return SPH_OK; }
     if (int rcRead = readInts(c, c->counters + which, 1, value)) return rcRead;
     return SPH_OK;
 }

@@ -684,8 +684,10 @@ __device__ __forceinline__ void block_count(bool pred, int* __restrict__ blockCo
     if (threadIdx.x == 0) blockCount[blockIdx.x] = (waveCnt[0] + waveCnt[1]) + (waveCnt[2] + waveCnt[3]);
 }
 
+// overwrite != 0: the counter was reset by the host since it was last written (sph_reset_counter defers
+// the zeroing to here instead of launching a 4-byte fill every frame)
 __global__ __launch_bounds__(kBlock) void k_sum_into(const int* __restrict__ blockCount, int nBlocks,
-                                                     int* __restrict__ counter) {
+                                                     int* __restrict__ counter, int overwrite) {
     __shared__ int ws[kBlock / 64];
     int m = 0;
     for (int b = threadIdx.x; b < nBlocks; b += kBlock) m += blockCount[b];
@@ -694,7 +696,10 @@ __global__ __launch_bounds__(kBlock) void k_sum_into(const int* __restrict__ blo
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = m;
     __syncthreads();
     const int tot = (ws[0] + ws[1]) + (ws[2] + ws[3]);
-    if (threadIdx.x == 0 && tot) atomicAdd(counter, tot);
+    if (threadIdx.x == 0) {
+        if (overwrite) *counter = tot;
+        else if (tot) atomicAdd(counter, tot);
+    }
 }
 
 // CS_BoundObs kernel; in slab mode ghost copies are counted by their owner.
