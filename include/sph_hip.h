@@ -150,7 +150,7 @@ int  sph_download_particles(sph_ctx* ctx, void* aos72, int n);
 
 /* ---- grid buffers ---------------------------------------------------------------------- */
 /* SPH.cs:156-157 / 339-345: (re)allocation of GridCounts[cells] and GridIndices[cells*cap].
- * The engine keeps cellStart/cellEnd[cells] + a sorted id list instead (no cells*cap array). */
+ * The engine keeps one cumulative cell table (a counting sort by cell) instead (no cells*cap array). */
 int  sph_resize_grid(sph_ctx* ctx, int rx, int ry, int rz, int max_per_cell);
 
 /* ---- parameters ------------------------------------------------------------------------ */

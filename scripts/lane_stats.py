@@ -58,3 +58,16 @@ print(f"density: groups/lane mean {lane_groups.mean():.1f}; wave executes {wave_
 print(f"force: hits/lane mean {h.mean():.1f}; wave executes max {h.max(1).mean():.1f} (efficiency {h.mean()/h.max(1).mean():.2f})")
 hs = np.sort(h, axis=1)
 print(f"force: if lanes were sorted by hits in blocks of 256 -> wave max mean {np.sort(hits[:len(hits)//256*256].reshape(-1,256),axis=1).reshape(-1,4,64).max(2).mean():.1f}")
+words = ((groups * 4 + 31) // 32)          # upper estimate of mask words per row (groups are 4-candidate units)
+wtot = np.zeros(len(pid), dtype=np.int64)
+t = 0
+for dz in (-1, 0, 1):
+    for dy in (-1, 0, 1):
+        y, z = cy + dy, cz + dz
+        ok = (y >= 0) & (y < ry) & (z >= 0) & (z < rz)
+        xlo, xhi = np.clip(cx - 1, 0, rx - 1), np.clip(cx + 1, 0, rx - 1)
+        base = (np.clip(y, 0, ry - 1) + ry * np.clip(z, 0, rz - 1)) * rx
+        ln = np.where(ok, cum[base + xhi + 1] - cum[base + xlo], 0)
+        wtot += (ln + 31) // 32
+mw = wtot[:m].reshape(-1, 64).max(1)
+print(f"mask words/particle mean {wtot.mean():.1f} max {wtot.max()}; particles > 16 words: {(wtot > 16).mean()*100:.2f} %; waves with such a lane: {(mw > 16).mean()*100:.1f} %; > 24: {(mw > 24).mean()*100:.1f} %")
