@@ -406,6 +406,24 @@ def bench_main(args, rank, local_rank, world):
     viol = comm.allreduce_sum(se.halo_violations)
     overflow = comm.allreduce_sum(eng.read_counter(abi.CTR_BIN_OVERFLOW))
     force_ms = comm.allreduce_max(tm["force_ms"])
+    # The same per-GPU load on ONE GPU, no slabs (every rank runs it on its own GPU, concurrently): what
+    # "weak scaling" compares with.  bench.py --gpus 1 runs config 3 (1 M particles), a different workload.
+    solo = None
+    if os.environ.get("SPH_BENCH_SOLO", "1") != "0":
+        eng.destroy()
+        eng = abi.Engine(local_rank)
+        s1 = scenes.config5(eng, gpus=1, per_gpu=per_gpu)
+        s1.sph.use_step_frame = True
+        s1.start()
+        for _ in range(args.warmup):
+            s1.frame()
+        eng.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            s1.frame()
+        eng.synchronize()
+        solo_dt = comm.allreduce_max(time.perf_counter() - t1)
+        solo = per_gpu * s1.sph.subSteps * args.steps / solo_dt
     if rank == 0:
         sub = sc.sph.subSteps
         n_local = se.n
@@ -418,7 +436,11 @@ def bench_main(args, rank, local_rank, world):
                                    f"8 ghost planes, one neighbour message per face per frame ({backend} send/recv)",
                        "particles": n_total, "sub_steps": sub, "parallelism": f"slab{world}",
                        "halo_violations": viol, "bin_overflow_cells": overflow,
-                       "exchange_ms_per_step_rank0": se.exchange_s / args.steps * 1e3},
+                       "exchange_ms_per_step_rank0": se.exchange_s / args.steps * 1e3,
+                       "one_gpu_same_load": None if solo is None else {
+                           "value": solo, "workload": f"config5, {per_gpu} particles, one GPU, no slabs (slowest of the "
+                                                      f"{world} GPUs, run concurrently)",
+                           "weak_scaling_efficiency": n_total * sub * args.steps / dt / (world * solo)}},
             "roofline": {"bound": "hbm", "kernel": "k_force_xsph_hits (CS_ForceXSPH), slowest rank", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                          "avg_launch_ms": force_ms},
