@@ -32,7 +32,8 @@ __global__ __launch_bounds__(kBlock) void k_clear(int n, float4* __restrict__ ac
 struct RowRange { int a, e; };
 
 
-constexpr int kMaskWords = 16;   // hit-mask words per particle (one 64-byte line); rows start on word boundaries
+constexpr int kMaskWords = 24;   // hit-mask words per particle (rows start on word boundaries); ~9-11 are in use at fluid densities
+constexpr int kMaskStage = 16;   // of which the density kernel stages this many in LDS (the rest, rare, go straight to memory)
 
 // XCD-aware workgroup -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs, each with
 // its own 4 MiB L2; consecutive tiles of the slot order share most of their neighbour rows, so runs
@@ -152,7 +153,8 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
     // same ranges and falls back to scanning).  Words are staged in LDS and written out once at
     // the end, 16 bytes at a time: word-by-word global stores left every particle's line
     // half-written in L2 for the whole kernel and cost 150 B of HBM writes per particle.
-    __shared__ uint32_t maskStage[kMaskWords][kBlock];
+    __shared__ uint32_t maskStage[kMaskStage][kBlock];
+    uint32_t* const mrowG = hitMask ? hitMask + (size_t)s * kMaskWords : nullptr;
     const bool recording = hitMask && !capped;
     uint32_t word = 0;
     int sh = 0, wi = 0;
@@ -198,7 +200,8 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
                 word |= (h0 | (h1 << 1) | (h2 << 2) | (h3 << 3)) << sh;
                 sh += 4;
                 if (sh == 32) {
-                    if (wi < kMaskWords) maskStage[wi][threadIdx.x] = word;
+                    if (wi < kMaskStage) maskStage[wi][threadIdx.x] = word;
+                    else if (wi < kMaskWords) mrowG[wi] = word;
                     wi++;
                     word = 0;
                     sh = 0;
@@ -206,7 +209,8 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
             }
         }
         if (recording && sh != 0) {                      // rows are padded to whole words
-            if (wi < kMaskWords) maskStage[wi][threadIdx.x] = word;
+            if (wi < kMaskStage) maskStage[wi][threadIdx.x] = word;
+            else if (wi < kMaskWords) mrowG[wi] = word;
             wi++;
             word = 0;
             sh = 0;
@@ -214,10 +218,10 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
         r = nxt;
     }
     if (recording) {
-        const int nWords = min(wi, kMaskWords);
-        uint4* const row = (uint4*)(hitMask + (size_t)s * kMaskWords);
+        const int nWords = min(wi, kMaskStage);
+        uint4* const row = (uint4*)mrowG;
 #pragma unroll
-        for (int q = 0; q < kMaskWords / 4; q++)
+        for (int q = 0; q < kMaskStage / 4; q++)
             if (q * 4 < nWords)
                 row[q] = make_uint4(maskStage[q * 4][threadIdx.x], maskStage[q * 4 + 1][threadIdx.x],
                                     maskStage[q * 4 + 2][threadIdx.x], maskStage[q * 4 + 3][threadIdx.x]);
@@ -445,10 +449,11 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
                                                             const int* __restrict__ phaseMismatch, int zeroDeadAcc) {
     // one buffer, two uses: (a) per lane the non-empty mask words and the slot of their bit 0,
     // (b) the scan path's hit FIFO.  Every thread only touches its own column.
-    static_assert(2 * kMaskWords >= kHitQueue, "the FIFO lives in the word list's LDS");
-    __shared__ int lds[2 * kMaskWords][kBlock];
+    static_assert(kMaskWords + 9 >= kHitQueue, "the FIFO lives in the word list's LDS");
+    __shared__ int lds[kMaskWords + 9][kBlock];
+    __shared__ uint8_t codeOf[kMaskWords][kBlock];       // (row << 3) | word-in-row of every kept word
     int (*const wordOf)[kBlock] = lds;                   // [kMaskWords]
-    int (*const baseOf)[kBlock] = lds + kMaskWords;      // [kMaskWords]
+    int (*const rowA)[kBlock] = lds + kMaskWords;        // [9] first slot of every row
     const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
     const int s = xcd_tile(blockIdx.x, gridDim.x, P.xcdRun) * kBlock + threadIdx.x;
     const ForceSelf me = force_load_self(P, s, posM, velIn, rhoP);
@@ -461,7 +466,8 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
 #pragma unroll
         for (int t = 0; t < 9; t++) {
             rr[t] = row_range(P, cellCum, c, t % 3 - 1, t / 3 - 1, me.live);
-            nWords += (rr[t].e - rr[t].a + 31) >> 5;
+            const int nw = (rr[t].e - rr[t].a + 31) >> 5;
+            nWords += nw > 8 ? kMaskWords + 1 : nw;      // the word-in-row code has three bits
         }
     }
     if (capped || __any(nWords > kMaskWords)) {
@@ -476,17 +482,18 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
                 wordOf[q * 4][tid] = (int)v.x; wordOf[q * 4 + 1][tid] = (int)v.y;
                 wordOf[q * 4 + 2][tid] = (int)v.z; wordOf[q * 4 + 3][tid] = (int)v.w;
             }
-        // 2) keep the non-empty words, each with the slot its bit 0 stands for (in place: the write
-        //    position never overtakes the read position)
+        // 2) keep the non-empty words, each with its row and its place in the row (in place: the
+        //    write position never overtakes the read position)
         int cnt = 0, idx = 0;
 #pragma unroll
         for (int t = 0; t < 9; t++) {
+            rowA[t][tid] = rr[t].a;
             const int nw = (rr[t].e - rr[t].a + 31) >> 5;
             for (int k = 0; k < nw; k++, idx++) {
                 const int w = wordOf[idx][tid];
                 if (w != 0) {
                     wordOf[cnt][tid] = w;
-                    baseOf[cnt][tid] = rr[t].a + (k << 5);
+                    codeOf[cnt][tid] = (uint8_t)((t << 3) | k);
                     cnt++;
                 }
             }
@@ -500,7 +507,8 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
         auto pop = [&](int& j) -> bool {
             if (w == 0 && li < cnt) {
                 w = (uint32_t)wordOf[li][tid];
-                base = baseOf[li][tid];
+                const int code = codeOf[li][tid];
+                base = rowA[code >> 3][tid] + ((code & 7) << 5);     // slot of the word's bit 0
                 li++;
             }
             if (w == 0) { j = me.sl; return false; }
