@@ -393,7 +393,7 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false)
             PackedNbr nbr{packed ? c->nbrA : nullptr, c->nbrB, s.velV, s.origId, c->phaseOfId,
                           c->slab ? (const uint8_t*)s.phase : (const uint8_t*)nullptr};
             hipLaunchKernelGGL(k_density_pressure_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.rho0,
-                               s.rhoP, c->cellCum, c->counters, c->useHitMask ? c->hitMask : (uint32_t*)nullptr, nbr,
+                               s.rhoP, c->cellCum, c->counters, c->useHitMask ? c->hitMask : (uint32_t*)nullptr, c->capacity, nbr,
                                c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr, c->blockInts);
             if (c->slab)
                 hipLaunchKernelGGL(k_slab_shift_reduce, dim3(1), dim3(kBlock), 0, c->stream, c->blockInts, nb,
@@ -421,11 +421,11 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false)
                 }
                 const PhaseConsts ph{m[0], m[1], m[2], m[3], v[0], v[1], v[2], v[3]};
                 hipLaunchKernelGGL(k_force_xsph_hits<true>, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV,
-                                   s.rhoP, s.acc, velOut, c->cellCum, c->counters, c->hitMask, c->nbrA, c->nbrB, ph,
+                                   s.rhoP, s.acc, velOut, c->cellCum, c->counters, c->hitMask, c->capacity, c->nbrA, c->nbrB, ph,
                                    c->slab ? (const int*)c->phaseMismatch : (const int*)nullptr, fused ? 1 : 0);
             } else if (c->maskValid) {
                 hipLaunchKernelGGL(k_force_xsph_hits<false>, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV,
-                                   s.rhoP, s.acc, velOut, c->cellCum, c->counters, c->hitMask, (const float4*)nullptr,
+                                   s.rhoP, s.acc, velOut, c->cellCum, c->counters, c->hitMask, c->capacity, (const float4*)nullptr,
                                    (const float4*)nullptr, PhaseConsts{}, (const int*)nullptr, fused ? 1 : 0);
             } else {
                 hipLaunchKernelGGL(k_force_xsph_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV,

@@ -117,7 +117,8 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
                                                                   float2* __restrict__ rhoP,
                                                                   const int* __restrict__ cellCum,
                                                                   const int* __restrict__ counters,
-                                                                  uint32_t* __restrict__ hitMask, PackedNbr nbr,
+                                                                  uint32_t* __restrict__ hitMask, int maskStride,
+                                                                  PackedNbr nbr,
                                                                   const uint32_t* __restrict__ slabKeys,
                                                                   int* __restrict__ slabShift) {
     const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
@@ -154,7 +155,9 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
     // the end, 16 bytes at a time: word-by-word global stores left every particle's line
     // half-written in L2 for the whole kernel and cost 150 B of HBM writes per particle.
     __shared__ uint32_t maskStage[kMaskStage][kBlock];
-    uint32_t* const mrowG = hitMask ? hitMask + (size_t)s * kMaskWords : nullptr;
+    // words 0..15 of a particle live in one 64-byte line; the rest (crowded particles only) in a second array
+    uint32_t* const mrowG = hitMask ? hitMask + (size_t)s * kMaskStage : nullptr;
+    uint32_t* const mrowHi = hitMask ? hitMask + (size_t)maskStride * kMaskStage + (size_t)s * (kMaskWords - kMaskStage) - kMaskStage : nullptr;
     const bool recording = hitMask && !capped;
     uint32_t word = 0;
     int sh = 0, wi = 0;
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
                 sh += 4;
                 if (sh == 32) {
                     if (wi < kMaskStage) maskStage[wi][threadIdx.x] = word;
-                    else if (wi < kMaskWords) mrowG[wi] = word;
+                    else if (wi < kMaskWords) mrowHi[wi] = word;
                     wi++;
                     word = 0;
                     sh = 0;
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
         }
         if (recording && sh != 0) {                      // rows are padded to whole words
             if (wi < kMaskStage) maskStage[wi][threadIdx.x] = word;
-            else if (wi < kMaskWords) mrowG[wi] = word;
+            else if (wi < kMaskWords) mrowHi[wi] = word;
             wi++;
             word = 0;
             sh = 0;
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
                                                             float4* __restrict__ acc, float4* __restrict__ velOut,
                                                             const int* __restrict__ cellCum,
                                                             const int* __restrict__ counters,
-                                                            const uint32_t* __restrict__ hitMask,
+                                                            const uint32_t* __restrict__ hitMask, int maskStride,
                                                             const float4* __restrict__ nbrA,
                                                             const float4* __restrict__ nbrB, PhaseConsts ph,
                                                             const int* __restrict__ phaseMismatch, int zeroDeadAcc) {
@@ -474,11 +477,13 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
         force_scan(P, A, me, c, capped, posM, velIn, rhoP, cellCum, lds);
     } else {
         // 1) the particle's mask row -> LDS (16 bytes at a time, only the part in use)
-        const uint4* __restrict__ mrow = (const uint4*)(hitMask + (size_t)me.sl * kMaskWords);
+        const uint4* __restrict__ mlo = (const uint4*)(hitMask + (size_t)me.sl * kMaskStage);
+        const uint4* __restrict__ mhi = (const uint4*)(hitMask + (size_t)maskStride * kMaskStage +
+                                                       (size_t)me.sl * (kMaskWords - kMaskStage)) - kMaskStage / 4;
 #pragma unroll
         for (int q = 0; q < kMaskWords / 4; q++)
             if (q * 4 < nWords) {
-                const uint4 v = mrow[q];
+                const uint4 v = q < kMaskStage / 4 ? mlo[q] : mhi[q];
                 wordOf[q * 4][tid] = (int)v.x; wordOf[q * 4 + 1][tid] = (int)v.y;
                 wordOf[q * 4 + 2][tid] = (int)v.z; wordOf[q * 4 + 3][tid] = (int)v.w;
             }
