@@ -74,7 +74,13 @@ struct sph_ctx {
     int lastForceVariant = -1;
 
     int* counters = nullptr;          // SPH_CTR_COUNT ints on the device
-    bool collisionsResetPending = false;   // sph_reset_counter(COLLISIONS) seen; applied by the next k_sum_into
+    // Collision counter (SPH_CTR_COLLISIONS), kept lazily: the boundary pass leaves one count per workgroup
+    // in blockCollide; they are folded into the device counter only when somebody reads it (or before the
+    // next pass overwrites them).  SPH.cs:190 resets the counter every frame and reads it never, so the
+    // usual frame pays neither a fill nor a reduction launch.
+    bool collisionsResetPending = false;   // the counter's stored value is void: the next fold overwrites it
+    int collideFoldBlocks = 0;             // > 0: blockCollide[0 .. this) holds counts not yet folded
+    int* blockCollide = nullptr;
     int* hostInts = nullptr;          // 16 pinned ints: landing zone of the small device -> host reads
 
     // slab decomposition (multi-GPU)
@@ -153,11 +159,11 @@ void freeParticles(sph_ctx* c) {
         devFree(c->keys[k]); devFree(c->vals[k]);
     }
     devFree(c->color); devFree(c->phaseOfId); devFree(c->sid);
-    devFree(c->aosStage); devFree(c->recStage); devFree(c->blockInts); devFree(c->hitMask); devFree(c->nbrA); devFree(c->nbrB);
+    devFree(c->aosStage); devFree(c->recStage); devFree(c->blockInts); devFree(c->blockCollide); devFree(c->hitMask); devFree(c->nbrA); devFree(c->nbrB);
     c->recStageCap = 0;
     if (c->pinned) (void)hipHostFree(c->pinned);
     c->pinned = nullptr; c->pinnedBytes = 0;
-    c->capacity = 0; c->n = 0;
+    c->capacity = 0; c->n = 0; c->collideFoldBlocks = 0;
 }
 
 void freeGrid(sph_ctx* c) {
@@ -366,6 +372,17 @@ int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
     return SPH_OK;
 }
 
+// Fold the per-workgroup collision counts of the last boundary pass into the device counter.
+int foldCollisions(sph_ctx* c) {
+    if (c->collideFoldBlocks <= 0) return SPH_OK;
+    hipLaunchKernelGGL(k_sum_into, dim3(1), dim3(kBlock), 0, c->stream, c->blockCollide, c->collideFoldBlocks,
+                       c->counters + SPH_CTR_COLLISIONS, c->collisionsResetPending ? 1 : 0);
+    CHECK_LAUNCH(c);
+    c->collideFoldBlocks = 0;
+    c->collisionsResetPending = false;
+    return SPH_OK;
+}
+
 int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false) {
     const int n = c->n;
     c->dp.n = n;
@@ -441,23 +458,21 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false)
         case SPH_K_VV_FULL_STEP:
             if (fused) {   // + CS_BoundObs (+ CS_VelocityDamping after the last sub-step), one pass
                 c->maskValid = false;
+                if (int rcFold = foldCollisions(c)) return rcFold;
                 hipLaunchKernelGGL(k_full_bound_damp, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, s.acc,
-                                   c->blockInts, c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr,
+                                   c->blockCollide, c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr,
                                    lastSub ? 1 : 0);
-                hipLaunchKernelGGL(k_sum_into, dim3(1), dim3(kBlock), 0, c->stream, c->blockInts, nb,
-                                   c->counters + SPH_CTR_COLLISIONS, c->collisionsResetPending ? 1 : 0);
-                c->collisionsResetPending = false;
+                c->collideFoldBlocks = nb;
                 break;
             }
             hipLaunchKernelGGL(k_full_step, dim3(nb), dim3(kBlock), 0, c->stream, n, c->dp.dt, s.velV, s.acc);
             break;
         case SPH_K_BOUND_OBS:
             c->maskValid = false;
-            hipLaunchKernelGGL(k_bound_obs, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, c->blockInts,
+            if (int rcFold = foldCollisions(c)) return rcFold;
+            hipLaunchKernelGGL(k_bound_obs, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, c->blockCollide,
                                c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr);
-            hipLaunchKernelGGL(k_sum_into, dim3(1), dim3(kBlock), 0, c->stream, c->blockInts, nb,
-                               c->counters + SPH_CTR_COLLISIONS, c->collisionsResetPending ? 1 : 0);
-                c->collisionsResetPending = false;
+            c->collideFoldBlocks = nb;
             break;
         case SPH_K_VELOCITY_DAMPING:
             hipLaunchKernelGGL(k_velocity_damping, dim3(nb), dim3(kBlock), 0, c->stream, n, s.velV);
@@ -549,6 +564,7 @@ static int allocCapacity(sph_ctx* c, int n) {
     if (!rc) rc = devAlloc(c, &c->phaseOfId, n);
     if (!rc) rc = devAlloc(c, &c->sid, n);
     if (!rc) rc = devAlloc(c, &c->blockInts, (size_t)blocksFor(n) + 1);
+    if (!rc) rc = devAlloc(c, &c->blockCollide, (size_t)blocksFor(n) + 1);
     if (!rc) rc = devAlloc(c, &c->hitMask, (size_t)n * kMaskWords);
     if (!rc) rc = devAlloc(c, &c->nbrA, (size_t)n);
     if (!rc) rc = devAlloc(c, &c->nbrB, (size_t)n);
@@ -774,6 +790,7 @@ int sph_reset_counter(sph_ctx* c, int which) {
     HIP_TRY(c, hipSetDevice(c->device));
     if (which == SPH_CTR_COLLISIONS) {   // SPH.cs:190 does this every frame: no launch, the next boundary pass overwrites
         c->collisionsResetPending = true;
+        c->collideFoldBlocks = 0;        // counts not folded yet are void too
         return SPH_OK;
     }
     HIP_TRY(c, hipMemsetAsync(c->counters + which, 0, sizeof(int), c->stream));
@@ -786,7 +803,10 @@ int sph_read_counter(sph_ctx* c, int which, int* value) {
     if (which < 0 || which >= SPH_CTR_COUNT || !value) return fail(c, SPH_E_INVALID, "bad counter %d", which);
     HIP_TRY(c, hipSetDevice(c->device));
     if (which == SPH_CTR_MAX_PLANE_SHIFT && c->cachedShift >= 0) { *value = c->cachedShift; return SPH_OK; }
-    if (which == SPH_CTR_COLLISIONS && c->collisionsResetPending) { *value = 0; return SPH_OK; }
+    if (which == SPH_CTR_COLLISIONS) {
+        if (int rcFold = foldCollisions(c)) return rcFold;
+        if (c->collisionsResetPending) { *value = 0; return SPH_OK; }
+    }
     if (int rcRead = readInts(c, c->counters + which, 1, value)) return rcRead;
     return SPH_OK;
 }
