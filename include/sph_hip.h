@@ -147,6 +147,12 @@ int  sph_alloc_particles(sph_ctx* ctx, int n);
 int  sph_upload_particles(sph_ctx* ctx, const void* aos72, int n);
 /* SPH.cs:287  particleBuffer.GetData(array): n records of 72 B, id order.  Synchronises. */
 int  sph_download_particles(sph_ctx* ctx, void* aos72, int n);
+/* Render feed.  In the reference the renderer binds the simulation's ComputeBuffer itself
+ * (SPH.cs:166-170 material.SetBuffer("_ParticleBuffer", particleBuffer); ParticleRender.shader:54-67 reads the
+ * 72-byte records, id = SV_VertexID).  Here: the same n records, id order, written into a DEVICE buffer of the
+ * caller on the ctx's GPU (n * 72 bytes; checked against the extent of its allocation), enqueued on the ctx's stream -- no host copy, does not
+ * synchronise.  Not available in slab mode. */
+int  sph_export_particles_device(sph_ctx* ctx, void* dev_aos72, int n);
 
 /* ---- grid buffers ---------------------------------------------------------------------- */
 /* SPH.cs:156-157 / 339-345: (re)allocation of GridCounts[cells] and GridIndices[cells*cap].

@@ -26,7 +26,7 @@ SLAB_RECORD_BYTES = 64
 # every symbol include/sph_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "sph_create", "sph_destroy", "sph_last_error", "sph_version", "sph_alloc_particles",
-    "sph_upload_particles", "sph_download_particles", "sph_resize_grid", "sph_set_params",
+    "sph_upload_particles", "sph_download_particles", "sph_export_particles_device", "sph_resize_grid", "sph_set_params",
     "sph_set_delta_time", "sph_set_phase_table", "sph_set_phase_ids", "sph_apply_phase_table",
     "sph_dispatch", "sph_step_frame", "sph_synchronize", "sph_reset_counter", "sph_read_counter",
     "sph_download_grid", "sph_download_neighbors", "sph_get_timings", "sph_device_pointer",
@@ -146,6 +146,7 @@ def load_library() -> C.CDLL:
     lib.sph_alloc_particles.argtypes = [vp, ip]
     lib.sph_upload_particles.argtypes = [vp, vp, ip]
     lib.sph_download_particles.argtypes = [vp, vp, ip]
+    lib.sph_export_particles_device.argtypes = [vp, vp, ip]
     lib.sph_resize_grid.argtypes = [vp, ip, ip, ip, ip]
     lib.sph_set_params.argtypes = [vp, C.POINTER(SphParams)]
     lib.sph_set_delta_time.argtypes = [vp, C.c_float]
@@ -223,6 +224,10 @@ class Engine:
         out = np.empty((self.n, PARTICLE_FLOATS), dtype=np.float32)
         self._ck(self.lib.sph_download_particles(self.h, _ptr(out), self.n))
         return out
+
+    def export_particles_device(self, dev_ptr: int, n=None):
+        """Render feed: the 72-byte records (id order) into a DEVICE buffer of n * 72 bytes; asynchronous."""
+        self._ck(self.lib.sph_export_particles_device(self.h, C.c_void_p(dev_ptr), self.n if n is None else n))
 
     def resize_grid(self, rx, ry, rz, cap):
         self._ck(self.lib.sph_resize_grid(self.h, rx, ry, rz, cap))

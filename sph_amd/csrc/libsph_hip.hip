@@ -629,6 +629,30 @@ int sph_download_particles(sph_ctx* c, void* aos72, int n) {
     return SPH_OK;
 }
 
+// Render feed: the 72-byte records straight into a DEVICE buffer of the caller (what ParticleRender.shader binds as
+// _ParticleBuffer), no host copy, no synchronisation.
+int sph_export_particles_device(sph_ctx* c, void* dev_aos72, int n) {
+    if (!c) return SPH_E_INVALID;
+    if (c->slab) return fail(c, SPH_E_STATE, "id-ordered AoS transfer is not available in slab mode (use sph_slab_download)");
+    if (!dev_aos72) return fail(c, SPH_E_INVALID, "null device buffer");
+    if (n != c->n || n <= 0) return fail(c, SPH_E_INVALID, "export count %d != allocated %d", n, c->n);
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, dev_aos72) != hipSuccess || at.type != hipMemoryTypeDevice || at.device != c->device) {
+        (void)hipGetLastError();
+        return fail(c, SPH_E_INVALID, "buffer is not device memory of GPU %d", c->device);
+    }
+    hipDeviceptr_t base = nullptr; size_t span = 0;
+    if (hipMemGetAddressRange(&base, &span, (hipDeviceptr_t)dev_aos72) != hipSuccess ||
+        (const char*)dev_aos72 + (size_t)n * SPH_PARTICLE_BYTES > (const char*)base + span || ((uintptr_t)dev_aos72 & 3)) {
+        (void)hipGetLastError();
+        return fail(c, SPH_E_INVALID, "device buffer is smaller than %d records of %d bytes (or misaligned)", n, SPH_PARTICLE_BYTES);
+    }
+    hipLaunchKernelGGL(k_export_aos, dim3(blocksFor(n)), dim3(kBlock), 0, c->stream, n, (float*)dev_aos72, curSet(c), c->color);
+    CHECK_LAUNCH(c);
+    return SPH_OK;
+}
+
 int sph_resize_grid(sph_ctx* c, int rx, int ry, int rz, int max_per_cell) {
     if (!c) return SPH_E_INVALID;
     if (rx <= 0 || ry <= 0 || rz <= 0 || max_per_cell <= 0)

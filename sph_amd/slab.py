@@ -162,8 +162,14 @@ class NeighbourComm:
             if n_from_r:
                 recvs.append((buf_r, right))
         self._xfer(sends, recvs)
-        if self.stage_cpu and self.device is not None and self.torch.device(self.device).type != "cpu":
-            buf_l, buf_r = buf_l.to(self.device), buf_r.to(self.device)
+        if self.stage_cpu:
+            if self.device is not None and self.torch.device(self.device).type != "cpu":
+                buf_l, buf_r = buf_l.to(self.device), buf_r.to(self.device)
+        elif sends or recvs:
+            # RCCL: wait() only orders torch's stream behind the transfer.  The engine works on its own
+            # stream (it reads the received records, and next frame's pack overwrites the send buffers),
+            # so the host waits here for both directions.
+            torch.cuda.current_stream(self.device).synchronize()
         return buf_l, buf_r
 
     def allreduce_sum(self, value: int) -> int:

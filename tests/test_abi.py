@@ -70,3 +70,59 @@ def test_no_product_code_touches_the_oracle():
                     if re.search(r"\bimport\s+oracle|from\s+oracle|liboracle|ora_[a-z]+\(", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def _c_struct_fields(name):
+    """[(field, array_len or 1)] of `typedef struct name {...}` in the header, declaration order."""
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    body = re.search(r"typedef struct %s \{(.*?)\}" % name, src, flags=re.S).group(1)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ctype, rest = decl.split(None, 1)
+        for item in rest.split(","):
+            m = re.match(r"\s*(\w+)(?:\[(\d+)\])?\s*$", item)
+            out.append((m.group(1), int(m.group(2) or 1), ctype))
+    return out
+
+
+def _cs_struct_fields(src, name):
+    body = re.search(r"struct %s\s*\{(.*?)\n    \}" % name, src, flags=re.S).group(1)
+    body = re.sub(r"//.*", "", body)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        m = re.match(r"public\s+(fixed\s+)?(\w+)\s+(.*)$", decl, flags=re.S)
+        for item in m.group(3).split(","):
+            mm = re.match(r"\s*(\w+)(?:\[(\d+)\])?\s*$", item)
+            out.append((mm.group(1), int(mm.group(2) or 1), m.group(2)))
+    return out
+
+
+def test_csharp_binding_matches_header():
+    """csharp/SphNative.cs cannot be compiled here (no .NET): check it textually against the header instead --
+    every DllImport names a declared entry point, every non-slab entry point is bound, and the blittable structs
+    have the header's fields in the header's order with the same array lengths and 4-byte scalar types."""
+    src = open(os.path.join(ROOT, "csharp", "SphNative.cs")).read()
+    bound = re.findall(r"public static extern \w+ (sph_[a-z_]+)\(", src)
+    declared = declared_functions()
+    assert len(bound) == len(set(bound))
+    assert set(bound) <= set(declared), set(bound) - set(declared)
+    unbound = {d for d in declared if d not in bound}
+    assert all(d.startswith("sph_slab_") or d in ("sph_device_pointer", "sph_get_stream") for d in unbound), unbound
+    ctype_of = {"uint32_t": "uint", "int32_t": "int", "float": "float"}
+    for c_name, cs_name in (("sph_params", "SphParams"), ("sph_phase", "SphPhase")):
+        want = [(f, n, ctype_of[t]) for f, n, t in _c_struct_fields(c_name)]
+        got = _cs_struct_fields(src, cs_name)
+        norm = lambda s: s.replace("_", "").lower()
+        assert [(norm(f), n, t) for f, n, t in got] == [(norm(f), n, t) for f, n, t in want], cs_name
+    assert len(_cs_struct_fields(src, "SphParticle")) == abi.PARTICLE_FLOATS
+    t = _cs_struct_fields(src, "SphTimings")
+    assert [x[2] for x in t] == ["float"] * 8 + ["int"] and len(_c_struct_fields("sph_timings")) == 9
+    kern = re.search(r"enum SphKernel\s*\{(.*?)\}", src, flags=re.S).group(1)
+    ids = dict((k.strip(), int(v)) for k, v in (kv.split("=") for kv in kern.replace("\n", " ").split(",")))
+    assert [k for k, _ in sorted(ids.items(), key=lambda kv: kv[1])] == [n[3:] for n in abi.KERNEL_NAMES]
