@@ -223,7 +223,8 @@ typedef struct sph_slab_record {       /* 64 bytes: what travels between slabs *
 } sph_slab_record;
 
 /* Local grid = global planes [x_offset, x_offset + rx_local) (rx_local from sph_resize_grid); planes
- * [own_lo, own_hi) (GLOBAL coordinates) are owned.  rx_global <= 0 switches slab mode off. */
+ * [own_lo, own_hi) (GLOBAL coordinates) are owned.  rx_global <= 0 switches slab mode off.  May be called again
+ * between frames to move the cut (see sph_slab_plane_counts). */
 int  sph_slab_configure(sph_ctx* ctx, int rx_global, int x_offset, int own_lo, int own_hi);
 /* Capacity-based allocation for a slab whose population changes every frame. */
 int  sph_slab_reserve(sph_ctx* ctx, int capacity);
@@ -245,6 +246,14 @@ int  sph_slab_pack(sph_ctx* ctx, int left_below, int right_from, void* dev_left,
  * the exact number after the build.  Does not synchronise. */
 int  sph_slab_rebuild(sph_ctx* ctx, int keep_lo, int keep_hi, const void* dev_from_left, int n_from_left,
                       const void* dev_from_right, int n_from_right, int* n_local);
+/* Load balance: particles per LOCAL cell plane (owned and ghost planes alike) as binned by the last grid build,
+ * counts[n_planes] with n_planes = the local x resolution.  Read from the cell table (no particle pass); needs
+ * the grid of the last frame, i.e. call it before sph_slab_rebuild.  Synchronises.
+ * Moving a slab's cut: sph_slab_configure + sph_resize_grid with the new ranges BEFORE that frame's
+ * sph_slab_pack; ownership (who sends what) stays that of the last grid build until the next one, so a frame's
+ * messages carry whatever changes hands.  The driver must keep every new face, plus the ghost width, inside the
+ * two slabs that were adjacent to the old face (sph_amd/slab.py: SlabEngine.rebalance). */
+int  sph_slab_plane_counts(sph_ctx* ctx, int32_t* counts, int n_planes);
 /* Current local particle count (owned + ghosts). */
 int  sph_particle_count(sph_ctx* ctx, int* n);
 

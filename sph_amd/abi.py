@@ -31,7 +31,7 @@ EXPORTS = [
     "sph_dispatch", "sph_step_frame", "sph_synchronize", "sph_reset_counter", "sph_read_counter",
     "sph_download_grid", "sph_download_neighbors", "sph_get_timings", "sph_device_pointer",
     "sph_get_stream", "sph_slab_configure", "sph_slab_reserve", "sph_slab_upload", "sph_slab_download",
-    "sph_slab_pack", "sph_slab_rebuild", "sph_particle_count",
+    "sph_slab_pack", "sph_slab_rebuild", "sph_slab_plane_counts", "sph_particle_count",
 ]
 
 
@@ -169,6 +169,7 @@ def load_library() -> C.CDLL:
     lib.sph_slab_download.argtypes = [vp, vp, ip, ip, C.POINTER(ip)]
     lib.sph_slab_pack.argtypes = [vp, ip, ip, vp, ip, vp, ip, C.POINTER(ip), C.POINTER(ip)]
     lib.sph_slab_rebuild.argtypes = [vp, ip, ip, vp, ip, vp, ip, C.POINTER(ip)]
+    lib.sph_slab_plane_counts.argtypes = [vp, vp, ip]
     lib.sph_particle_count.argtypes = [vp, C.POINTER(ip)]
     for name in EXPORTS:
         fn = getattr(lib, name)
@@ -323,6 +324,11 @@ class Engine:
         self._ck(self.lib.sph_slab_rebuild(self.h, keep_lo, keep_hi, dev_left, n_left, dev_right, n_right, C.byref(n)))
         self.n = n.value
         return n.value
+
+    def slab_plane_counts(self, rx_local) -> np.ndarray:
+        out = np.zeros(rx_local, dtype=np.int32)
+        self._ck(self.lib.sph_slab_plane_counts(self.h, _ptr(out), rx_local))
+        return out
 
     def particle_count(self) -> int:
         n = C.c_int(0)

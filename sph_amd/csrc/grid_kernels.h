@@ -40,9 +40,22 @@ __device__ __forceinline__ int3 cell_unclamped(const DevParams& P, float x, floa
 // [keepLo, keepHi) stay; slots from nOld on are records just received from the slab neighbours and
 // stay if their plane is in range.  Everything else gets no key, is not counted and is not placed:
 // the counting sort itself is the compaction, no separate copy of the survivors.
+// Who owned a slot at the last grid build: its key there, decoded with THAT build's local grid (the slab's
+// cut may have moved since: sph_slab_configure before the next build).  keys == null: everything was owned.
+struct OwnedRef {
+    const uint32_t* keys;
+    int rx, ownLo, ownHi;            // local resolution and owned local planes of the build that wrote `keys`
+};
+
+__device__ __forceinline__ bool was_owned(const OwnedRef& R, int s) {
+    if (!R.keys) return true;
+    const int plane = (int)(R.keys[s] % (uint32_t)R.rx);
+    return plane >= R.ownLo && plane < R.ownHi;
+}
+
 struct SlabFilter {
     int active, keepLo, keepHi, nOld;
-    const uint32_t* oldKeys;         // keys of the last build (null before the first one: everything was owned)
+    OwnedRef old;                    // the last build (keys null before the first one)
 };
 
 __global__ __launch_bounds__(kBlock) void k_hash_count(DevParams P, const float4* __restrict__ posM,
@@ -54,10 +67,7 @@ __global__ __launch_bounds__(kBlock) void k_hash_count(DevParams P, const float4
     uint32_t key = 0xFFFFFFFFu;                          // lanes past the end: a run of their own, no atomic
     bool take = s < P.n;
     if (take && F.active) {
-        if (s < F.nOld && F.oldKeys) {
-            const int plane = (int)(F.oldKeys[s] % (uint32_t)P.rx);
-            take = plane >= P.ownLo && plane < P.ownHi;
-        }
+        if (s < F.nOld) take = was_owned(F.old, s);
         if (take) {
             const int g = min(max((int)floorf((posM[s].x - P.minBound[0]) / P.cellSize), 0), P.rxg - 1);
             take = g >= F.keepLo && g < F.keepHi;
@@ -242,6 +252,24 @@ __global__ __launch_bounds__(kBlock) void k_scatter_by_id(DevParams P, const uin
     const int y = ((tile % P.ryT) << kTileYLog) + (in & (kTileY - 1));
     const int z = ((tile / P.ryT) << kTileZLog) + (in >> kTileYLog);
     out[origId[s]] = (uint32_t)(x + y * P.rx + z * P.rx * P.ry);
+}
+
+// Particles per local cell plane at the last grid build, from the cumulative table alone (slab mode: what the
+// driver cuts the slabs by).  rows = table rows (rows of the padding tiles are empty); a workgroup sums
+// kPlaneRows rows, its threads striding over x (coalesced: x is the fastest index of a key).
+constexpr int kPlaneRows = 64;
+__global__ __launch_bounds__(kBlock) void k_plane_counts(const int* __restrict__ cellCum, int rx, long long rows,
+                                                         int* __restrict__ out) {
+    const long long r0 = (long long)blockIdx.x * kPlaneRows;
+    const long long r1 = r0 + kPlaneRows < rows ? r0 + kPlaneRows : rows;
+    for (int x = threadIdx.x; x < rx; x += kBlock) {
+        int sum = 0;
+        for (long long r = r0; r < r1; r++) {
+            const long long b = r * rx + x;
+            sum += cellCum[b + 1] - cellCum[b];
+        }
+        if (sum) atomicAdd(&out[x], sum);
+    }
 }
 
 }  // namespace sph

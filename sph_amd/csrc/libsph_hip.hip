@@ -91,6 +91,8 @@ struct sph_ctx {
                                       // mode: plane shifts of the density kernel (capacity / 256 + 1 ints)
     int* phaseMismatch = nullptr;     // device flag: some slab record's statics are not its phase's row (PhaseCheck)
     SlabFilter filter{};              // set by sph_slab_rebuild, consumed by the next grid build
+    OwnedRef ownedRef{nullptr, 1, 0, 0};   // who owned which slot at the last grid build (survives a re-cut of the slab)
+    int* planeCounts = nullptr; int planeCountsCap = 0;   // sph_slab_plane_counts
     int cachedShift = -1;             // SPH_CTR_MAX_PLANE_SHIFT as read along with sph_slab_pack's counts (-1 = not cached)
     bool slabPackedOff = false;       // the phase table changed after the records were uploaded
     SlabRecord* recStage = nullptr;   // device staging for slab upload / download
@@ -159,7 +161,7 @@ void freeParticles(sph_ctx* c) {
         devFree(c->keys[k]); devFree(c->vals[k]);
     }
     devFree(c->color); devFree(c->phaseOfId); devFree(c->sid);
-    devFree(c->aosStage); devFree(c->recStage); devFree(c->blockInts); devFree(c->blockCollide); devFree(c->hitMask); devFree(c->nbrA); devFree(c->nbrB);
+    devFree(c->aosStage); devFree(c->recStage); devFree(c->planeCounts); c->planeCountsCap = 0; devFree(c->blockInts); devFree(c->blockCollide); devFree(c->hitMask); devFree(c->nbrA); devFree(c->nbrB);
     c->recStageCap = 0;
     if (c->pinned) (void)hipHostFree(c->pinned);
     c->pinned = nullptr; c->pinnedBytes = 0;
@@ -326,6 +328,7 @@ int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
     if (rc) return rc;
     const SlabFilter filter = c->filter;
     c->filter.active = 0;
+    if (c->slab) c->ownedRef = OwnedRef{c->keys[1], c->dp.rx, c->dp.ownLo, c->dp.ownHi};   // as of THIS build
     if (n == 0) {   // an empty slab: the zeroed table is its grid
         c->gridValid = true;
         return SPH_OK;
@@ -1014,6 +1017,7 @@ int sph_slab_upload(sph_ctx* c, const sph_slab_record* records, int n) {
     }
     c->cur = 0; c->velCur = 0; c->gridValid = false; c->maskValid = false;
     c->n = n;
+    c->ownedRef.keys = nullptr;       // everything uploaded is owned
     c->slabPackedOff = false;
     HIP_TRY(c, hipMemsetAsync(c->phaseMismatch, 0, sizeof(int), c->stream));
     if (n == 0) return SPH_OK;
@@ -1039,7 +1043,7 @@ int sph_slab_download(sph_ctx* c, sph_slab_record* records, int max_records, int
     if (rc) return rc;
     HIP_TRY(c, hipMemsetAsync(c->slabCounts, 0, 4 * sizeof(int), c->stream));
     hipLaunchKernelGGL(k_slab_export, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->dp, curSet(c),
-                       c->gridValid ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr, owned_only, c->recStage,
+                       c->ownedRef, owned_only, c->recStage,
                        c->n, c->slabCounts);
     CHECK_LAUNCH(c);
     int cnt = 0;
@@ -1063,7 +1067,7 @@ int sph_slab_pack(sph_ctx* c, int left_below, int right_from, void* dev_left, in
     if (c->n == 0) return SPH_OK;
     HIP_TRY(c, hipMemsetAsync(c->slabCounts, 0, 4 * sizeof(int), c->stream));
     hipLaunchKernelGGL(k_slab_pack, dim3((c->n + kBlock * kKeepItems - 1) / (kBlock * kKeepItems)), dim3(kBlock), 0, c->stream, c->dp, curSet(c),
-                       c->gridValid ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr, left_below, right_from,
+                       c->ownedRef, left_below, right_from,
                        (SlabRecord*)dev_left, cap_left, (SlabRecord*)dev_right, cap_right, c->slabCounts);
     CHECK_LAUNCH(c);
     // the two message sizes and -- same synchronisation -- the frame's plane shift, which the driver asks for next
@@ -1103,11 +1107,33 @@ int sph_slab_rebuild(sph_ctx* c, int keep_lo, int keep_hi, const void* dev_from_
         hipLaunchKernelGGL(k_slab_append_at, dim3(blocksFor(n_from_right)), dim3(kBlock), 0, c->stream,
                            (const SlabRecord*)dev_from_right, n_from_right, cur, nOld + n_from_left, phaseCheck(c));
     CHECK_LAUNCH(c);
-    c->filter = SlabFilter{1, keep_lo, keep_hi, nOld,
-                           c->gridValid ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr};
+    c->filter = SlabFilter{1, keep_lo, keep_hi, nOld, c->ownedRef};
     c->n = nOld + n_from_left + n_from_right;
     c->gridValid = false; c->maskValid = false;
     *n_local = c->n;       // upper bound until the grid build; sph_particle_count afterwards
+    return SPH_OK;
+}
+
+int sph_slab_plane_counts(sph_ctx* c, int32_t* counts, int n_planes) {
+    if (!c) return SPH_E_INVALID;
+    if (!c->slab) return fail(c, SPH_E_STATE, "sph_slab_configure first");
+    if (!counts || n_planes != c->rx) return fail(c, SPH_E_INVALID, "expected %d plane counts (the local x resolution), got %d", c->rx, n_planes);
+    if (!c->gridValid) return fail(c, SPH_E_STATE, "plane counts need the grid of the last frame (call before sph_slab_rebuild)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n_planes > c->planeCountsCap) {
+        devFree(c->planeCounts);
+        c->planeCountsCap = 0;
+        int rc = devAlloc(c, &c->planeCounts, (size_t)n_planes);
+        if (rc) return rc;
+        c->planeCountsCap = n_planes;
+    }
+    HIP_TRY(c, hipMemsetAsync(c->planeCounts, 0, sizeof(int) * (size_t)n_planes, c->stream));
+    const long long rows = c->tableCells / c->rx;
+    hipLaunchKernelGGL(k_plane_counts, dim3((unsigned)((rows + kPlaneRows - 1) / kPlaneRows)), dim3(kBlock), 0, c->stream,
+                       (const int*)c->cellCum, c->rx, rows, c->planeCounts);
+    CHECK_LAUNCH(c);
+    HIP_TRY(c, hipMemcpyAsync(counts, c->planeCounts, sizeof(int) * (size_t)n_planes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SPH_OK;
 }
 

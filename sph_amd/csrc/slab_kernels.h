@@ -25,13 +25,6 @@ __device__ __forceinline__ int global_plane(const DevParams& P, float x) {
     return min(max(c, 0), P.rxg - 1);
 }
 
-// owned at the last grid build?  (all particles are "owned" before the first build)
-__device__ __forceinline__ bool was_owned(const DevParams& P, const uint32_t* __restrict__ sortedKeys, int s) {
-    if (!sortedKeys) return true;
-    const int plane = (int)(sortedKeys[s] % (uint32_t)P.rx);
-    return plane >= P.ownLo && plane < P.ownHi;
-}
-
 // wave-aggregated append: one atomic per wave, slot = base + rank among the appending lanes
 __device__ __forceinline__ int wave_append(bool pred, int* counter) {
     const unsigned long long m = __ballot(pred);
@@ -91,7 +84,7 @@ __device__ __forceinline__ void store_record(const StateSet& st, int k, const Sl
 // atomic (the band particles are the two ends of every cell row, so most waves hold a few; one
 // atomic per wave would again serialise on the two counters).
 constexpr int kKeepItems = 8;
-__global__ __launch_bounds__(kBlock) void k_slab_pack(DevParams P, StateSet st, const uint32_t* __restrict__ sortedKeys,
+__global__ __launch_bounds__(kBlock) void k_slab_pack(DevParams P, StateSet st, OwnedRef owned,
                                                       int leftBelow, int rightFrom, SlabRecord* __restrict__ left,
                                                       int capLeft, SlabRecord* __restrict__ right, int capRight,
                                                       int* __restrict__ counts) {
@@ -105,7 +98,7 @@ __global__ __launch_bounds__(kBlock) void k_slab_pack(DevParams P, StateSet st, 
     for (int it = 0; it < kKeepItems; it++) {
         const int s = first + it * kBlock;
         bool toL = false, toR = false;
-        if (s < P.n && was_owned(P, sortedKeys, s)) {
+        if (s < P.n && was_owned(owned, s)) {
             const int g = global_plane(P, st.posM[s].x);
             toL = g < leftBelow;
             toR = g >= rightFrom;
@@ -150,11 +143,11 @@ __global__ __launch_bounds__(kBlock) void k_slab_append_at(const SlabRecord* __r
 }
 
 // Export of the local set as records (owned only, or everything), compacted.
-__global__ __launch_bounds__(kBlock) void k_slab_export(DevParams P, StateSet st, const uint32_t* __restrict__ sortedKeys,
+__global__ __launch_bounds__(kBlock) void k_slab_export(DevParams P, StateSet st, OwnedRef owned,
                                                         int ownedOnly, SlabRecord* __restrict__ out, int cap,
                                                         int* __restrict__ count) {
     const int s = blockIdx.x * kBlock + threadIdx.x;
-    const bool take = s < P.n && (!ownedOnly || was_owned(P, sortedKeys, s));
+    const bool take = s < P.n && (!ownedOnly || was_owned(owned, s));
     const int k = wave_append(take, count);
     if (take && k < cap) out[k] = make_record(st, s);
 }

@@ -25,7 +25,13 @@ half-step); the engine measures that shift every frame (SPH_CTR_MAX_PLANE_SHIFT)
 counts violations.  Point-to-point only: each GPU talks to at most two peers over their direct xGMI
 links; there is no collective on the data path.
 
-Limits of this round: static slab boundaries (equal plane counts), static boundary cube,
+Load balance (SlabEngine(rebalance_every=K)): every K frames the ranks add up their per-plane particle counts
+(read from the cell table, `sph_slab_plane_counts`; one small all-reduce of RX ints -- the only collective, and
+not on the data path), cut the planes into equal shares and move their faces by at most `max_cut_shift` planes.
+Ownership stays that of the last grid build until the next one, so the frame's ordinary face messages carry
+whatever changes hands; no extra exchange.  Results stay bit-identical to a one-GPU run.
+
+Limits of this round: static boundary cube,
 subSteps == 1 (a ghost refresh per extra sub-step is not implemented), migration to adjacent slabs
 only (particles conserved is asserted by `count_global`).
 """
@@ -48,6 +54,27 @@ def slab_ranges(rx_global: int, world: int):
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
+def balanced_cuts(hist, old_cuts, min_width: int, max_shift: int):
+    """Cut points (len world+1) that split `hist` (particles per global plane) into equal shares, each face at most
+    `max_shift` planes from its old place and every slab at least `min_width` planes wide.  Needs old slabs that
+    are themselves at least `min_width` wide (then the two constraints never contradict each other)."""
+    hist = np.asarray(hist, dtype=np.int64)
+    rx, world = hist.shape[0], len(old_cuts) - 1
+    cum = np.concatenate([[0], np.cumsum(hist)])
+    total = int(cum[-1])
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        c = int(np.searchsorted(cum, target, side="left"))
+        if c > 0 and abs(cum[c - 1] - target) <= abs(cum[min(c, rx)] - target):
+            c -= 1
+        lo = max(old_cuts[r] - max_shift, cuts[-1] + min_width)
+        hi = min(old_cuts[r] + max_shift, rx - (world - r) * min_width)
+        cuts.append(min(max(c, lo), hi))
+    cuts.append(rx)
+    return cuts
+
+
 # ------------------------------------------------------------------------------------------------
 # ports: how the driver talks to one rank's engine.  Messages are torch uint8 tensors [n, 64].
 # ------------------------------------------------------------------------------------------------
@@ -67,6 +94,18 @@ class DevicePort:
         self.e.slab_configure(rx_global, x_offset, own_lo, own_hi)
         self.e.slab_reserve(capacity)
         self.e.resize_grid(rx_local, ry, rz, cap)
+
+    def reconfigure(self, rx_global, x_offset, rx_local, ry, rz, cap, own_lo, own_hi):
+        """Move the slab's cut between two frames (before that frame's pack)."""
+        self.e.slab_configure(rx_global, x_offset, own_lo, own_hi)
+        self.e.resize_grid(rx_local, ry, rz, cap)
+
+    def owned_plane_histogram(self, rx_global, x_offset, rx_local, own_lo, own_hi):
+        """Particles per GLOBAL plane in this rank's owned planes, as binned by the last grid build."""
+        local = self.e.slab_plane_counts(rx_local)
+        hist = np.zeros(rx_global, dtype=np.int64)
+        hist[own_lo:own_hi] = local[own_lo - x_offset:own_hi - x_offset]
+        return hist
 
     def upload_owned(self, records):
         self.e.slab_upload(records)
@@ -177,6 +216,12 @@ class NeighbourComm:
         self.dist.all_reduce(t)
         return int(t.item())
 
+    def allreduce_sum_array(self, a: np.ndarray) -> np.ndarray:
+        """Element-wise sum over the ranks of a small int64 array (the per-plane histogram of a re-cut)."""
+        t = self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(self._dev())
+        self.dist.all_reduce(t)
+        return t.cpu().numpy()
+
     def allreduce_max(self, value: float) -> float:
         t = self.torch.tensor([value], dtype=self.torch.float64, device=self._dev())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -193,10 +238,17 @@ class SlabEngine:
     """Stands where sph_amd.abi.Engine stands for host.SPH, for one rank of a slab-decomposed run."""
 
     def __init__(self, port, comm: NeighbourComm, rank: int, world: int, ghost_planes: int = 8,
-                 capacity_factor: float = 1.6):
+                 capacity_factor: float = 1.6, rebalance_every: int = 0, max_cut_shift: Optional[int] = None,
+                 rebalance_threshold: float = 1.05):
         self.port, self.comm, self.rank, self.world = port, comm, rank, world
         self.ghost = int(ghost_planes)
         self.capacity_factor = capacity_factor
+        self.rebalance_every = int(rebalance_every)           # 0: static, equal plane counts
+        self.max_cut_shift = self.ghost if max_cut_shift is None else int(max_cut_shift)
+        self.rebalance_threshold = float(rebalance_threshold)  # re-cut when max share / mean share exceeds it
+        self.cuts = None
+        self.recuts = 0
+        self.imbalance = 1.0
         self.e = port.e
         self.n_global = 0
         self.n = 0
@@ -261,11 +313,46 @@ class SlabEngine:
             return
         self.grid = (rx, ry, rz, cap)
         self.cells = rx * ry * rz
-        x0, x1 = slab_ranges(rx, self.world)[self.rank]
-        if x1 - x0 < 2 * self.ghost and self.world > 1:
-            raise ValueError(f"slab of {x1 - x0} planes is narrower than 2 x {self.ghost} ghost planes")
+        ranges = slab_ranges(rx, self.world)
+        self.cuts = [r[0] for r in ranges] + [rx]
+        x0, x1 = ranges[self.rank]
+        narrowest = min(b - a for a, b in ranges)
+        if narrowest < 2 * self.ghost and self.world > 1:
+            raise ValueError(f"slab of {narrowest} planes is narrower than 2 x {self.ghost} ghost planes")
+        if self.rebalance_every and self.world > 1 and narrowest < self.min_width:
+            raise ValueError(f"moving cuts need slabs of at least 2 x {self.ghost} ghost planes + {self.max_cut_shift} "
+                             f"planes of cut shift; the narrowest has {narrowest}")
         self.own = (x0, x1)
         self.keep = (max(x0 - self.ghost, 0), min(x1 + self.ghost, rx))
+
+    @property
+    def min_width(self):
+        # A new face plus the ghost width must stay inside the two slabs next to the old face, also for particles
+        # that moved since the last build (at most ghost/2 - 1 planes, the halo condition): width >= 2 ghost + shift.
+        return 2 * self.ghost + self.max_cut_shift
+
+    def rebalance(self):
+        """Re-cut the slabs by particle count.  Collective (every rank calls it in the same frame); must run before
+        the frame's pack, while the grid of the last frame is still valid."""
+        rx, ry, rz, cap = self.grid
+        hist = self.port.owned_plane_histogram(rx, self.keep[0], self.keep[1] - self.keep[0], self.own[0], self.own[1])
+        hist = self.comm.allreduce_sum_array(hist)
+        cum = np.concatenate([[0], np.cumsum(hist)])
+        shares = np.diff(cum[np.asarray(self.cuts)])
+        mean = max(float(cum[-1]) / self.world, 1.0)
+        self.imbalance = float(shares.max()) / mean
+        if self.imbalance <= self.rebalance_threshold:
+            return False
+        cuts = balanced_cuts(hist, self.cuts, self.min_width, self.max_cut_shift)
+        if cuts == self.cuts:
+            return False
+        self.cuts = cuts
+        x0, x1 = cuts[self.rank], cuts[self.rank + 1]
+        self.own = (x0, x1)
+        self.keep = (max(x0 - self.ghost, 0), min(x1 + self.ghost, rx))
+        self.port.reconfigure(rx, self.keep[0], self.keep[1] - self.keep[0], ry, rz, cap, x0, x1)
+        self.recuts += 1
+        return True
 
     def set_params(self, p):
         self._params = p
@@ -292,6 +379,8 @@ class SlabEngine:
     # ---- the per-frame exchange
     def exchange(self):
         t0 = time.perf_counter()
+        if self.rebalance_every and self.world > 1 and self.frames > 0 and self.frames % self.rebalance_every == 0:
+            self.rebalance()
         x0, x1 = self.own
         rx = self.grid[0]
         left_below = x0 + self.ghost if self.rank > 0 else 0
@@ -383,7 +472,10 @@ def bench_main(args, rank, local_rank, world):
     port = DevicePort(eng, local_rank, msg_capacity=max(per_gpu // 4, 65536))
     comm = NeighbourComm(rank, world, torch.device("cuda", local_rank), backend=backend,
                          msg_capacity=max(per_gpu // 4, 65536))
-    se = SlabEngine(port, comm, rank, world, ghost_planes=8)
+    # config 5 starts balanced and stays so (G equal blocks side by side); SPH_BENCH_REBALANCE=K re-cuts the
+    # slabs by particle count every K frames anyway (0 = static cuts)
+    se = SlabEngine(port, comm, rank, world, ghost_planes=8,
+                    rebalance_every=int(os.environ.get("SPH_BENCH_REBALANCE", "0")))
     sc = scenes.config5(se, gpus=world, per_gpu=per_gpu)
     sc.sph.use_step_frame = True
     sc.start()
@@ -442,6 +534,7 @@ def bench_main(args, rank, local_rank, world):
                                    f"8 ghost planes, one neighbour message per face per frame ({backend} send/recv)",
                        "particles": n_total, "sub_steps": sub, "parallelism": f"slab{world}",
                        "halo_violations": viol, "bin_overflow_cells": overflow,
+                       "rebalance_every": se.rebalance_every, "recuts": se.recuts,
                        "exchange_ms_per_step_rank0": se.exchange_s / args.steps * 1e3,
                        "one_gpu_same_load": None if solo is None else {
                            "value": solo, "workload": f"config5, {per_gpu} particles, one GPU, no slabs (slowest of the "

@@ -52,6 +52,14 @@ class OraclePort:
         self.ora.resize_grid(rx_global, ry, rz, cap)
         self.e.cells = rx_global * ry * rz
 
+    def reconfigure(self, rx_global, x_offset, rx_local, ry, rz, cap, own_lo, own_hi):
+        self.own = (own_lo, own_hi)                # owned_mask stays that of the last build until the next one
+
+    def owned_plane_histogram(self, rx_global, x_offset, rx_local, own_lo, own_hi):
+        valid = self.ids != 0xFFFFFFFF
+        owned = valid if self.owned_mask is None else (self.owned_mask & valid)
+        return np.bincount(self._bin_plane[owned], minlength=rx_global).astype(np.int64)
+
     def _set_local(self, recs):
         recs = recs[np.argsort(recs["id"], kind="stable")]
         self.ids = recs["id"].copy()

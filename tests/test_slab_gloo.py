@@ -38,7 +38,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, frames, out_dir, step_frame):
+def _worker(rank, world, port, frames, out_dir, step_frame, ghost=8, rebalance_every=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -46,7 +46,8 @@ def _worker(rank, world, port, frames, out_dir, step_frame):
     from tests.slab_oracle_port import OraclePort
     oport = OraclePort(Oracle())
     comm = slab.NeighbourComm(rank, world, torch.device("cpu"), backend="gloo")
-    se = slab.SlabEngine(oport, comm, rank, world, ghost_planes=8)
+    se = slab.SlabEngine(oport, comm, rank, world, ghost_planes=ghost, rebalance_every=rebalance_every,
+                         max_cut_shift=4, rebalance_threshold=1.0)
     orig = se.set_params
 
     def set_params(p):
@@ -63,6 +64,7 @@ def _worker(rank, world, port, frames, out_dir, step_frame):
     recs = se.owned_records()
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), recs)
     np.save(os.path.join(out_dir, f"counts{rank}.npy"), np.array(counts))
+    np.save(os.path.join(out_dir, f"cuts{rank}.npy"), np.array(se.cuts + [se.recuts]))
     dist.destroy_process_group()
 
 
@@ -87,6 +89,53 @@ def test_two_slabs_equal_single_domain(tmp_path, oracle_built, step_frame):
     assert min(per_rank) > 0.1 * n                              # both slabs really hold fluid
     for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
         assert np.array_equal(got[:, sl], want[:, sl]), "slab run differs from the single-domain run"
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_moving_cuts_equal_single_domain(tmp_path, oracle_built, world):
+    """Load-balanced cuts: every 2 frames the ranks re-cut the planes by particle count (one all-reduce of the
+    per-plane histogram) -- the faces move, particles change owner through the ordinary face messages, and the
+    result is still the single-domain run bit for bit."""
+    frames = 7
+    from oracle.ora import Oracle
+    ref = Oracle()
+    sc = small_tank(ref)
+    sc.run(frames)
+    want = ref.download_particles()
+    n = want.shape[0]
+    mp.spawn(_worker, args=(world, _free_port(), frames, str(tmp_path), True, 4, 2), nprocs=world, join=True)
+    recs = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)])
+    cuts = [np.load(tmp_path / f"cuts{r}.npy").tolist() for r in range(world)]
+    assert all(c == cuts[0] for c in cuts), "ranks disagree about the cuts"
+    assert cuts[0][-1] >= 1, "the cuts never moved: the test does not exercise a re-cut"
+    assert cuts[0][:-1] != [r[0] for r in slab.slab_ranges(48, world)] + [48]
+    assert np.load(tmp_path / "counts0.npy").tolist() == [n] * frames
+    assert np.array_equal(np.sort(recs["id"]), np.arange(n, dtype=np.uint32))
+    got = abi.aos_from_records(recs[np.argsort(recs["id"])])
+    for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
+        assert np.array_equal(got[:, sl], want[:, sl]), "re-cut slab run differs from the single-domain run"
+
+
+def test_balanced_cuts_respect_width_and_shift():
+    rng = np.random.default_rng(1)
+    for _ in range(300):
+        world, g, d = int(rng.integers(2, 9)), int(rng.integers(1, 5)), int(rng.integers(1, 6))
+        mw = 2 * g + d
+        rx = int(world * mw + rng.integers(0, 200))
+        cuts = [(rx * r) // world for r in range(world + 1)]
+        for _ in range(5):
+            hist = rng.integers(0, 50, rx) * (rng.random(rx) < 0.3)
+            new = slab.balanced_cuts(hist, cuts, mw, d)
+            assert new[0] == 0 and new[-1] == rx
+            assert all(b - a >= mw for a, b in zip(new, new[1:])) and all(abs(a - b) <= d for a, b in zip(new, cuts))
+            cuts = new
+    # unconstrained, the shares come out equal to within one plane's population
+    hist = np.full(400, 10)
+    assert slab.balanced_cuts(hist, [0, 100, 200, 300, 400], 1, 400) == [0, 100, 200, 300, 400]
+    hist[:200] = 30
+    cuts = slab.balanced_cuts(hist, [0, 100, 200, 300, 400], 1, 400)
+    shares = np.diff(np.concatenate([[0], np.cumsum(hist)])[cuts])
+    assert shares.max() - shares.min() <= 30
 
 
 def test_slab_ranges_cover_the_grid():

@@ -15,14 +15,15 @@ from tests.test_slab_gloo import _free_port, small_tank
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, frames, out_dir, n, ghost, drop_phases):
+def _worker(rank, world, port, frames, out_dir, n, ghost, drop_phases, rebalance_every=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     eng = abi.Engine(0)
     dport = slab.DevicePort(eng, 0, msg_capacity=n)
     comm = slab.NeighbourComm(rank, world, torch.device("cuda", 0), backend="gloo")
-    se = slab.SlabEngine(dport, comm, rank, world, ghost_planes=ghost)
+    se = slab.SlabEngine(dport, comm, rank, world, ghost_planes=ghost, rebalance_every=rebalance_every,
+                         max_cut_shift=4, rebalance_threshold=1.0)
     if drop_phases:
         # records arrive without their spawn-box index: the second box's mass / viscosity / rest density
         # then disagree with row 0 of the phase table, and the engine has to notice (PhaseCheck) and
@@ -38,6 +39,7 @@ def _worker(rank, world, port, frames, out_dir, n, ghost, drop_phases):
         counts.append(se.count_global())
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), se.owned_records())
     np.save(os.path.join(out_dir, f"meta{rank}.npy"), np.array(counts + [se.halo_violations]))
+    np.save(os.path.join(out_dir, f"cuts{rank}.npy"), np.array(se.cuts + [se.recuts]))
     eng.destroy()
     dist.destroy_process_group()
 
@@ -65,3 +67,52 @@ def test_slabs_equal_single_engine_bitwise(tmp_path, world, ghost, drop_phases):
     got = abi.aos_from_records(recs[np.argsort(recs["id"])])
     for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
         assert np.array_equal(got[:, sl], want[:, sl]), f"{world} slabs differ from one engine"
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_moving_cuts_equal_single_engine_bitwise(tmp_path, world):
+    """Load-balanced cuts (sph_slab_plane_counts + sph_slab_configure between frames): the faces move every 2 frames,
+    ownership changes hands through the ordinary face messages, the result stays that of one engine bit for bit."""
+    frames, n = 9, 3000
+    eng = abi.Engine(0)
+    sc = small_tank(eng, n=n)
+    sc.sph.use_step_frame = True
+    sc.run(frames)
+    want = eng.download_particles()
+    eng.destroy()
+    n = want.shape[0]
+    mp.spawn(_worker, args=(world, _free_port(), frames, str(tmp_path), n, 4, False, 2), nprocs=world, join=True)
+    recs = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)])
+    meta = np.load(tmp_path / "meta0.npy")
+    cuts = [np.load(tmp_path / f"cuts{r}.npy").tolist() for r in range(world)]
+    assert all(c == cuts[0] for c in cuts) and cuts[0][-1] >= 1, f"cuts {cuts}"
+    assert meta[:-1].tolist() == [n] * frames and meta[-1] == 0
+    assert np.array_equal(np.sort(recs["id"]), np.arange(n, dtype=np.uint32))
+    got = abi.aos_from_records(recs[np.argsort(recs["id"])])
+    for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
+        assert np.array_equal(got[:, sl], want[:, sl]), f"{world} re-cut slabs differ from one engine"
+
+
+def test_plane_counts_equal_download():
+    """sph_slab_plane_counts (from the cell table) against the planes of the downloaded records."""
+    dist.init_process_group("gloo", rank=0, world_size=1, init_method=f"tcp://127.0.0.1:{_free_port()}")
+    try:
+        eng = abi.Engine(0)
+        se = slab.SlabEngine(slab.DevicePort(eng, 0, msg_capacity=4096),
+                             slab.NeighbourComm(0, 1, torch.device("cuda", 0), backend="gloo"), 0, 1)
+        sc = small_tank(se, n=3000)
+        sc.sph.use_step_frame = True
+        sc.start()
+        sc.run(3)
+        rx = se.grid[0]
+        counts = eng.slab_plane_counts(rx)
+        cs, ce = np.empty(eng.cells, dtype=np.int32), np.empty(eng.cells, dtype=np.int32)
+        eng._ck(eng.lib.sph_download_grid(eng.h, cs.ctypes.data, ce.ctypes.data, None, None))
+        assert counts.sum() == eng.particle_count()
+        per_cell = (ce - cs).astype(np.int64)          # reference cell order: x fastest (compute:127)
+        assert np.array_equal(counts, per_cell.reshape(-1, rx).sum(axis=0))
+        with pytest.raises(abi.SphError):
+            eng.slab_plane_counts(rx + 1)
+        eng.destroy()
+    finally:
+        dist.destroy_process_group()
