@@ -133,7 +133,10 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
         // behind a check -- serialises 32 k requests on one address: +70 us at 2 M particles.)
         __shared__ int waveShift[kBlock / 64];
         const int cx = search_cell(P, p.x, p.y, p.z).x;
-        int shift = valid ? abs(cx - ((int)(slabKeys[s] % (uint32_t)P.rx) + P.xoff)) : 0;
+        // owned particles only: a ghost is measured by its owner (the driver adds up the ranks' verdicts), and with
+        // subSteps > 1 the outermost ghosts are no longer right after the first sub-step and must not raise alarms
+        const int binned = valid ? (int)(slabKeys[s] % (uint32_t)P.rx) : 0;
+        int shift = valid && binned >= P.ownLo && binned < P.ownHi ? abs(cx - (binned + P.xoff)) : 0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) shift = max(shift, __shfl_xor(shift, o));
         if ((threadIdx.x & 63) == 0) waveShift[threadIdx.x >> 6] = shift;

@@ -20,9 +20,11 @@ beyond it.  The receiver keeps what falls into its local plane range: records in
 are immigrants (now owned), the others are ghosts.  The sender keeps its emigrants as ghosts.  Last
 frame's ghosts are dropped.  The frame then runs with NO further communication: ghosts are advanced
 redundantly (half-step and density are recomputed locally for them from identical inputs, hence
-bit-identical), which needs ghost_planes >= 2 * (1 + max plane shift of a particle during the
-half-step); the engine measures that shift every frame (SPH_CTR_MAX_PLANE_SHIFT) and the driver
-counts violations.  Point-to-point only: each GPU talks to at most two peers over their direct xGMI
+bit-identical), which needs ghost_planes >= 2 * subSteps * (1 + max plane shift of a particle against
+its frame-start plane): every sub-step a band of 2 * (1 + shift) planes at the outer edge of the ghost
+region stops being right (density there misses neighbours, then forces next to it use that density), and
+the owned planes must stay clear of it -- wider ghosts instead of a ghost refresh per sub-step.  The engine
+measures the shift every frame (SPH_CTR_MAX_PLANE_SHIFT, owned particles) and the driver counts violations.  Point-to-point only: each GPU talks to at most two peers over their direct xGMI
 links; there is no collective on the data path.
 
 Load balance (SlabEngine(rebalance_every=K)): every K frames the ranks add up their per-plane particle counts
@@ -31,9 +33,8 @@ not on the data path), cut the planes into equal shares and move their faces by 
 Ownership stays that of the last grid build until the next one, so the frame's ordinary face messages carry
 whatever changes hands; no extra exchange.  Results stay bit-identical to a one-GPU run.
 
-Limits of this round: static boundary cube,
-subSteps == 1 (a ghost refresh per extra sub-step is not implemented), migration to adjacent slabs
-only (particles conserved is asserted by `count_global`).
+Limits of this round: static boundary cube, migration to adjacent slabs only (particles conserved is
+asserted by `count_global`).
 """
 from __future__ import annotations
 
@@ -259,6 +260,7 @@ class SlabEngine:
         self._min_x = None
         self._cell = None
         self.halo_violations = 0
+        self.sub_steps = 1            # of the last frame (sets the halo width the frame needed)
         self.frames = 0
         self.exchange_s = 0.0
 
@@ -388,7 +390,7 @@ class SlabEngine:
         to_l, to_r = self.port.pack(left_below, right_from)
         if self.frames > 0 and self.world > 1:
             shift = self.e.read_counter(abi.CTR_MAX_PLANE_SHIFT)     # came back with pack's counts: no extra sync
-            if 2 * (1 + shift) > self.ghost:
+            if 2 * self.sub_steps * (1 + shift) > self.ghost:
                 self.halo_violations += 1
         from_l, from_r = self.comm.exchange(to_l, to_r)
         self.n = self.port.rebuild(self.keep[0], self.keep[1], from_l, from_r)
@@ -403,8 +405,7 @@ class SlabEngine:
             self.e.n = self.n
 
     def step_frame(self, sub_steps, time_step):
-        if sub_steps != 1 and self.world > 1:
-            raise NotImplementedError("slab mode supports subSteps == 1 (no per-sub-step ghost refresh yet)")
+        self.sub_steps = int(sub_steps)
         self.exchange()
         self.e.step_frame(sub_steps, time_step)
         self._refresh_count()
@@ -418,7 +419,12 @@ class SlabEngine:
             self.e.dispatch(kernel_id, self.n)
             if kernel_id == abi.K_BUILD_GRID:
                 self._refresh_count()
+        if kernel_id == abi.K_CLEAR_GRID:
+            self._half_steps = 0
+        elif kernel_id == abi.K_VV_HALF_STEP:
+            self._half_steps = getattr(self, "_half_steps", 0) + 1
         if kernel_id == abi.K_VELOCITY_DAMPING:
+            self.sub_steps = max(getattr(self, "_half_steps", 1), 1)
             self.frames += 1
 
     def synchronize(self):

@@ -13,7 +13,7 @@ from sph_amd import abi, scenes, slab
 from sph_amd.host import SPH, Scene, SpawnBox, Time, Transform
 
 
-def small_tank(engine, n=1500):
+def small_tank(engine, n=1500, sub_steps=1):
     """A tank 12 x 3 x 2 units (48 x 12 x 8 cells of 0.25); fluid straddling the slab cuts of a
     2-way (x = 0) and a 3-way (x = -2, +2) decomposition, moving across them."""
     cube = Transform(position=(0, 1.5, 0), localScale=(12, 3, 2))
@@ -25,7 +25,7 @@ def small_tank(engine, n=1500):
     boxes = [SpawnBox(na, (4.0, sa, sa), 20, 0.1, 0.2, position=(-0.5, 1.0, 0.0), initialVelocity=(1.5, 0, 0)),
              SpawnBox(nb, (2.0, sb, sb), 10, 0.05, 0.2, position=(1.5, 1.9, 0.0), initialVelocity=(-2.0, 0, 0))]
     f = dict(scenes.SCENE_COMMON)
-    f.update(gridResolution=8)          # min axis 2 / 8 -> cell 0.25
+    f.update(gridResolution=8, subSteps=sub_steps)          # min axis 2 / 8 -> cell 0.25
     sph = SPH(engine, **f, surfaceTensionCoefficient=0.1, xsphEpsilon=0.3, boundaryCube=cube, spawnBoxes=boxes)
     return Scene(sph, Time(), [])
 
@@ -38,7 +38,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, frames, out_dir, step_frame, ghost=8, rebalance_every=0):
+def _worker(rank, world, port, frames, out_dir, step_frame, ghost=8, rebalance_every=0, sub_steps=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -54,7 +54,7 @@ def _worker(rank, world, port, frames, out_dir, step_frame, ghost=8, rebalance_e
         oport.set_params_ref(p)
         orig(p)
     se.set_params = set_params
-    sc = small_tank(se)
+    sc = small_tank(se, sub_steps=sub_steps)
     sc.sph.use_step_frame = step_frame
     sc.start()
     counts = []
@@ -89,6 +89,25 @@ def test_two_slabs_equal_single_domain(tmp_path, oracle_built, step_frame):
     assert min(per_rank) > 0.1 * n                              # both slabs really hold fluid
     for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
         assert np.array_equal(got[:, sl], want[:, sl]), "slab run differs from the single-domain run"
+
+
+@pytest.mark.parametrize("step_frame", [True, False])
+def test_two_sub_steps_two_slabs_equal_single_domain(tmp_path, oracle_built, step_frame):
+    """subSteps = 2 with no ghost refresh between the sub-steps: the ghost region is wide enough (8 planes >=
+    2 x 2 x (1 + shift 1)) for the owned planes to stay clear of the band that goes stale."""
+    frames = 4
+    from oracle.ora import Oracle
+    ref = Oracle()
+    sc = small_tank(ref, sub_steps=2)
+    sc.run(frames)
+    want = ref.download_particles()
+    n = want.shape[0]
+    mp.spawn(_worker, args=(2, _free_port(), frames, str(tmp_path), step_frame, 8, 0, 2), nprocs=2, join=True)
+    recs = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(2)])
+    assert np.load(tmp_path / "counts0.npy").tolist() == [n] * frames
+    got = abi.aos_from_records(recs[np.argsort(recs["id"])])
+    for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
+        assert np.array_equal(got[:, sl], want[:, sl]), "two sub-steps: slab run differs from the single-domain run"
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -15,7 +15,7 @@ from tests.test_slab_gloo import _free_port, small_tank
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, frames, out_dir, n, ghost, drop_phases, rebalance_every=0):
+def _worker(rank, world, port, frames, out_dir, n, ghost, drop_phases, rebalance_every=0, sub_steps=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -30,7 +30,7 @@ def _worker(rank, world, port, frames, out_dir, n, ghost, drop_phases, rebalance
         # keep gathering mass and viscosity per particle
         add = se.add_rows
         se.add_rows = lambda first_id, rows, phase=0: add(first_id, rows, 0)
-    sc = small_tank(se, n=n)
+    sc = small_tank(se, n=n, sub_steps=sub_steps)
     sc.sph.use_step_frame = True
     sc.start()
     counts = []
@@ -91,6 +91,26 @@ def test_moving_cuts_equal_single_engine_bitwise(tmp_path, world):
     got = abi.aos_from_records(recs[np.argsort(recs["id"])])
     for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
         assert np.array_equal(got[:, sl], want[:, sl]), f"{world} re-cut slabs differ from one engine"
+
+
+def test_two_sub_steps_two_slabs_bitwise(tmp_path):
+    """subSteps = 2, no exchange between the sub-steps: 8 ghost planes >= 2 x 2 x (1 + shift) keep the owned planes
+    clear of the ghost band that goes stale; halo_violations (measured, owned particles) must stay 0."""
+    frames, n = 5, 3000
+    eng = abi.Engine(0)
+    sc = small_tank(eng, n=n, sub_steps=2)
+    sc.sph.use_step_frame = True
+    sc.run(frames)
+    want = eng.download_particles()
+    eng.destroy()
+    n = want.shape[0]
+    mp.spawn(_worker, args=(2, _free_port(), frames, str(tmp_path), n, 8, False, 0, 2), nprocs=2, join=True)
+    recs = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(2)])
+    meta = np.load(tmp_path / "meta0.npy")
+    assert meta[:-1].tolist() == [n] * frames and meta[-1] == 0, meta
+    got = abi.aos_from_records(recs[np.argsort(recs["id"])])
+    for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
+        assert np.array_equal(got[:, sl], want[:, sl]), "two sub-steps: 2 slabs differ from one engine"
 
 
 def test_plane_counts_equal_download():
