@@ -106,7 +106,11 @@ enum sph_counter {
                                  the last grid build (compute:126 clamps them)            */
     SPH_CTR_MAX_PLANE_SHIFT = 3, /* slab mode: max |search plane - binned plane| over the local
                                  particles in the last CS_DensityPressure (halo-width check)     */
-    SPH_CTR_COUNT        = 4
+    SPH_CTR_BAND_MISSES  = 4, /* slab mode with sph_slab_arm_pack: owned particles that ended the last frame in a
+                                 plane of the send range without being in a band workgroup, i.e. that were NOT
+                                 sent (can only happen when the halo condition is violated too); counted by
+                                 the grid build that follows                                                  */
+    SPH_CTR_COUNT        = 5
 };
 
 typedef struct sph_ctx sph_ctx;
@@ -246,6 +250,20 @@ int  sph_slab_pack(sph_ctx* ctx, int left_below, int right_from, void* dev_left,
  * the exact number after the build.  Does not synchronise. */
 int  sph_slab_rebuild(sph_ctx* ctx, int keep_lo, int keep_hi, const void* dev_from_left, int n_from_left,
                       const void* dev_from_right, int n_from_right, int* n_local);
+/* Exchange overlapped with compute.  sph_slab_arm_pack makes the NEXT sph_step_frame pack that frame's face
+ * messages itself (same selection and record contents as sph_slab_pack called after the frame), as early as
+ * the frame allows: the last sub-step's CS_ForceXSPH runs first on the workgroups (256 consecutive slots)
+ * that hold an owned particle binned within band_margin planes of the send range, the records are written
+ * with the rest of the frame applied on the fly, and only then the remaining workgroups run.  sph_step_frame
+ * returns as usual; sph_slab_pack_wait blocks until the records are complete -- while the GPU continues with the
+ * rest of the frame -- and returns the counts.  The caller then moves the buffers and calls sph_slab_rebuild,
+ * which is enqueued behind the frame.  band_margin must cover the planes a particle can move in one frame
+ * (ghost/2 does whenever the halo condition holds); particles that were missed are counted by the following
+ * grid build (SPH_CTR_BAND_MISSES).  left_below = 0 / right_from = global resolution: no neighbour on that side. */
+int  sph_slab_arm_pack(sph_ctx* ctx, int left_below, int right_from, int band_margin, void* dev_left, int cap_left,
+                       void* dev_right, int cap_right);
+/* n_band_workgroups (may be NULL): how many 256-slot workgroups ran before the pack (of ceil(n / 256)). */
+int  sph_slab_pack_wait(sph_ctx* ctx, int* n_left, int* n_right, int* n_band_workgroups);
 /* Load balance: particles per LOCAL cell plane (owned and ghost planes alike) as binned by the last grid build,
  * counts[n_planes] with n_planes = the local x resolution.  Read from the cell table (no particle pass); needs
  * the grid of the last frame, i.e. call it before sph_slab_rebuild.  Synchronises.

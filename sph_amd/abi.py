@@ -20,7 +20,7 @@ K_CLEAR, K_CLEAR_GRID, K_BUILD_GRID, K_DENSITY_PRESSURE, K_FORCE_XSPH, K_VV_HALF
 KERNEL_NAMES = ["CS_Clear", "CS_ClearGrid", "CS_BuildGrid", "CS_DensityPressure", "CS_ForceXSPH",
                 "CS_VvHalfStep", "CS_VvFullStep", "CS_BoundObs", "CS_VelocityDamping"]
 
-CTR_COLLISIONS, CTR_BIN_OVERFLOW, CTR_OUT_OF_GRID, CTR_MAX_PLANE_SHIFT = range(4)
+CTR_COLLISIONS, CTR_BIN_OVERFLOW, CTR_OUT_OF_GRID, CTR_MAX_PLANE_SHIFT, CTR_BAND_MISSES = range(5)
 SLAB_RECORD_BYTES = 64
 
 # every symbol include/sph_hip.h declares (checked by tests/test_abi.py)
@@ -31,7 +31,8 @@ EXPORTS = [
     "sph_dispatch", "sph_step_frame", "sph_synchronize", "sph_reset_counter", "sph_read_counter",
     "sph_download_grid", "sph_download_neighbors", "sph_get_timings", "sph_device_pointer",
     "sph_get_stream", "sph_slab_configure", "sph_slab_reserve", "sph_slab_upload", "sph_slab_download",
-    "sph_slab_pack", "sph_slab_rebuild", "sph_slab_plane_counts", "sph_particle_count",
+    "sph_slab_pack", "sph_slab_rebuild", "sph_slab_arm_pack", "sph_slab_pack_wait", "sph_slab_plane_counts",
+    "sph_particle_count",
 ]
 
 
@@ -169,6 +170,8 @@ def load_library() -> C.CDLL:
     lib.sph_slab_download.argtypes = [vp, vp, ip, ip, C.POINTER(ip)]
     lib.sph_slab_pack.argtypes = [vp, ip, ip, vp, ip, vp, ip, C.POINTER(ip), C.POINTER(ip)]
     lib.sph_slab_rebuild.argtypes = [vp, ip, ip, vp, ip, vp, ip, C.POINTER(ip)]
+    lib.sph_slab_arm_pack.argtypes = [vp, ip, ip, ip, vp, ip, vp, ip]
+    lib.sph_slab_pack_wait.argtypes = [vp, C.POINTER(ip), C.POINTER(ip), C.POINTER(ip)]
     lib.sph_slab_plane_counts.argtypes = [vp, vp, ip]
     lib.sph_particle_count.argtypes = [vp, C.POINTER(ip)]
     for name in EXPORTS:
@@ -324,6 +327,15 @@ class Engine:
         self._ck(self.lib.sph_slab_rebuild(self.h, keep_lo, keep_hi, dev_left, n_left, dev_right, n_right, C.byref(n)))
         self.n = n.value
         return n.value
+
+    def slab_arm_pack(self, left_below, right_from, band_margin, dev_left, cap_left, dev_right, cap_right):
+        self._ck(self.lib.sph_slab_arm_pack(self.h, left_below, right_from, band_margin, dev_left, cap_left, dev_right, cap_right))
+
+    def slab_pack_wait(self):
+        nl, nr, nb = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._ck(self.lib.sph_slab_pack_wait(self.h, C.byref(nl), C.byref(nr), C.byref(nb)))
+        self.band_workgroups = nb.value
+        return nl.value, nr.value
 
     def slab_plane_counts(self, rx_local) -> np.ndarray:
         out = np.zeros(rx_local, dtype=np.int32)

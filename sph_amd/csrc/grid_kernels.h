@@ -56,6 +56,10 @@ __device__ __forceinline__ bool was_owned(const OwnedRef& R, int s) {
 struct SlabFilter {
     int active, keepLo, keepHi, nOld;
     OwnedRef old;                    // the last build (keys null before the first one)
+    // overlap mode: the last frame packed its face messages from the band workgroups only (bandWg[slot >> 8]);
+    // an owned particle outside them that ended in a plane < sendLo or >= sendHi was NOT sent: counted
+    const uint8_t* bandWg;
+    int sendLo, sendHi;
 };
 
 __global__ __launch_bounds__(kBlock) void k_hash_count(DevParams P, const float4* __restrict__ posM,
@@ -66,13 +70,19 @@ __global__ __launch_bounds__(kBlock) void k_hash_count(DevParams P, const float4
     bool oog = false;
     uint32_t key = 0xFFFFFFFFu;                          // lanes past the end: a run of their own, no atomic
     bool take = s < P.n;
+    bool missed = false;
     if (take && F.active) {
         if (s < F.nOld) take = was_owned(F.old, s);
         if (take) {
             const int g = min(max((int)floorf((posM[s].x - P.minBound[0]) / P.cellSize), 0), P.rxg - 1);
+            missed = F.bandWg && s < F.nOld && !F.bandWg[s >> 8] && (g < F.sendLo || g >= F.sendHi);
             take = g >= F.keepLo && g < F.keepHi;
         }
         if (!take) keys[s] = 0xFFFFFFFFu;
+    }
+    if (F.bandWg) {
+        const unsigned long long mm = __ballot(missed);
+        if (mm && lane == 0) atomicAdd(&counters[SPH_CTR_BAND_MISSES], __popcll(mm));
     }
     if (take) {
         float4 p = posM[s];

@@ -92,8 +92,19 @@ struct sph_ctx {
     int* phaseMismatch = nullptr;     // device flag: some slab record's statics are not its phase's row (PhaseCheck)
     SlabFilter filter{};              // set by sph_slab_rebuild, consumed by the next grid build
     OwnedRef ownedRef{nullptr, 1, 0, 0};   // who owned which slot at the last grid build (survives a re-cut of the slab)
+    // exchange overlapped with compute (sph_slab_arm_pack): the next sph_step_frame packs the face messages itself,
+    // from the band workgroups, between the two launches of the last CS_ForceXSPH
+    struct ArmedPack { bool armed = false; int leftBelow = 0, rightFrom = 0, margin = 0; void* devL = nullptr; int capL = 0;
+                       void* devR = nullptr; int capR = 0; } armedPack;
+    uint8_t* wgBand = nullptr;        // per workgroup of 256 slots: 1 = holds a particle near a slab face
+    hipEvent_t packEvent = nullptr;   // recorded behind the in-frame pack
+    bool packPending = false;         // counts of an in-frame pack not collected yet (sph_slab_pack_wait)
+    int packCapL = 0, packCapR = 0;
+    bool bandValid = false;           // wgBand / bandSendLo / bandSendHi describe the frame that just ran
+    int bandSendLo = 0, bandSendHi = 0;
     int* planeCounts = nullptr; int planeCountsCap = 0;   // sph_slab_plane_counts
     int cachedShift = -1;             // SPH_CTR_MAX_PLANE_SHIFT as read along with sph_slab_pack's counts (-1 = not cached)
+    int cachedMisses = -1;            // SPH_CTR_BAND_MISSES as read along with the survivor count of a slab build
     bool slabPackedOff = false;       // the phase table changed after the records were uploaded
     SlabRecord* recStage = nullptr;   // device staging for slab upload / download
     size_t recStageCap = 0;
@@ -161,7 +172,7 @@ void freeParticles(sph_ctx* c) {
         devFree(c->keys[k]); devFree(c->vals[k]);
     }
     devFree(c->color); devFree(c->phaseOfId); devFree(c->sid);
-    devFree(c->aosStage); devFree(c->recStage); devFree(c->planeCounts); c->planeCountsCap = 0; devFree(c->blockInts); devFree(c->blockCollide); devFree(c->hitMask); devFree(c->nbrA); devFree(c->nbrB);
+    devFree(c->aosStage); devFree(c->recStage); devFree(c->planeCounts); c->planeCountsCap = 0; devFree(c->wgBand); devFree(c->blockInts); devFree(c->blockCollide); devFree(c->hitMask); devFree(c->nbrA); devFree(c->nbrB);
     c->recStageCap = 0;
     if (c->pinned) (void)hipHostFree(c->pinned);
     c->pinned = nullptr; c->pinnedBytes = 0;
@@ -226,6 +237,7 @@ void deriveParams(sph_ctx* c) {
     d.spikyGradFactor = -45.0f / (PI * powf(h, 6.0f));
     d.viscLapFactor = 45.0f / (PI * powf(h, 6.0f));
     d.lapColFactor = 1890.0f / (64.0f * PI * powf(h, 9.0f));
+    d.wgBand = nullptr; d.wgPhase = -1;
 }
 
 int checkReady(sph_ctx* c, bool needGrid) {
@@ -316,6 +328,7 @@ int clearGrid(sph_ctx* c, bool resetBuildCounters = false) {
     c->gridValid = false;
     c->maskValid = false;
     c->cachedShift = -1;
+    c->cachedMisses = -1;
     return SPH_OK;
 }
 
@@ -353,7 +366,14 @@ int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
     int nNew = n;
     if (filter.active) {
         // the survivors are what the table counted: one read, the only synchronisation of a slab rebuild
-        if (int rcRead = readInts(c, c->cellCum + c->tableCells, 1, &nNew)) return rcRead;
+        // (and, same synchronisation, the particles the last in-frame pack failed to send)
+        HIP_TRY(c, hipMemcpyAsync(c->hostInts, c->cellCum + c->tableCells, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        if (filter.bandWg)
+            HIP_TRY(c, hipMemcpyAsync(c->hostInts + 1, c->counters + SPH_CTR_BAND_MISSES, sizeof(int), hipMemcpyDeviceToHost,
+                                      c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        nNew = c->hostInts[0];
+        c->cachedMisses = filter.bandWg ? c->hostInts[1] : 0;
         c->n = nNew;
         c->dp.n = nNew;
         if (nNew == 0) { c->cur = 1 - c->cur; c->velCur = 1 - c->velCur; c->gridValid = true; return SPH_OK; }
@@ -386,9 +406,13 @@ int foldCollisions(sph_ctx* c) {
     return SPH_OK;
 }
 
-int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false) {
+// wgPhase (CS_ForceXSPH only): -1 = one launch over everything; 1 = band workgroups, then 0 = the rest -- two
+// launches that together are the one, writing the same velocity buffer (flipped after the second).
+int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false, int wgPhase = -1) {
     const int n = c->n;
     c->dp.n = n;
+    c->dp.wgBand = wgPhase >= 0 ? c->wgBand : (const uint8_t*)nullptr;
+    c->dp.wgPhase = wgPhase;
     if (n == 0 && id != SPH_K_CLEAR_GRID && id != SPH_K_BUILD_GRID) {   // an empty slab has nothing to launch
         if (id < SPH_K_CLEAR || id > SPH_K_VELOCITY_DAMPING) return fail(c, SPH_E_INVALID, "bad kernel id %d", id);
         return SPH_OK;
@@ -451,7 +475,7 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false)
                 hipLaunchKernelGGL(k_force_xsph_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV,
                                    s.rhoP, s.acc, velOut, c->cellCum, c->counters, fused ? 1 : 0);
             }
-            c->velCur = 1 - c->velCur;
+            if (wgPhase != 1) c->velCur = 1 - c->velCur;
             break;
         }
         case SPH_K_VV_HALF_STEP:
@@ -514,6 +538,7 @@ int sph_create(sph_ctx** out, int device_id) {
     }
     for (int r = 0; r < kTimingRing; r++)
         for (int k = 0; k < kNumEvents; k++) (void)hipEventCreate(&c->ev[r][k]);
+    (void)hipEventCreateWithFlags(&c->packEvent, hipEventDisableTiming);
     if (hipHostMalloc((void**)&c->hostInts, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void**)&c->counters, SPH_CTR_COUNT * sizeof(int)) != hipSuccess ||
         hipMalloc((void**)&c->slabCounts, 4 * sizeof(int)) != hipSuccess ||
@@ -542,6 +567,7 @@ int sph_destroy(sph_ctx* c) {
     for (int r = 0; r < kTimingRing; r++)
         for (int k = 0; k < kNumEvents; k++)
             if (c->ev[r][k]) (void)hipEventDestroy(c->ev[r][k]);
+    if (c->packEvent) (void)hipEventDestroy(c->packEvent);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SPH_OK;
@@ -568,6 +594,7 @@ static int allocCapacity(sph_ctx* c, int n) {
     if (!rc) rc = devAlloc(c, &c->sid, n);
     if (!rc) rc = devAlloc(c, &c->blockInts, (size_t)blocksFor(n) + 1);
     if (!rc) rc = devAlloc(c, &c->blockCollide, (size_t)blocksFor(n) + 1);
+    if (!rc && c->slab) rc = devAlloc(c, &c->wgBand, (size_t)blocksFor(n) + 1);
     if (!rc) rc = devAlloc(c, &c->hitMask, (size_t)n * kMaskWords);
     if (!rc) rc = devAlloc(c, &c->nbrA, (size_t)n);
     if (!rc) rc = devAlloc(c, &c->nbrB, (size_t)n);
@@ -778,6 +805,24 @@ int sph_step_frame(sph_ctx* c, int sub_steps, float time_step) {
     c->dp.n = c->n;
     if ((rc = buildGrid(c, true))) return rc;
     if (tl >= 2) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
+    // slab mode, sph_slab_arm_pack: this frame packs its own face messages (see slab_kernels.h)
+    const sph_ctx::ArmedPack ap = c->armedPack;
+    c->armedPack.armed = false;
+    c->bandValid = false;
+    const bool split = ap.armed && c->slab && c->n > 0 && c->wgBand;
+    int bandLo = 0, bandHi = 0;
+    if (ap.armed) {
+        if (c->packPending) return fail(c, SPH_E_STATE, "the previous in-frame pack was not collected (sph_slab_pack_wait)");
+        HIP_TRY(c, hipMemsetAsync(c->slabCounts, 0, 4 * sizeof(int), c->stream));
+        // no left (right) neighbour: left_below = 0 (right_from = global resolution), nothing is near that face
+        bandLo = ap.leftBelow > 0 ? ap.leftBelow + ap.margin : 0;
+        bandHi = ap.rightFrom < c->rxGlobal ? ap.rightFrom - ap.margin : c->rxGlobal;
+    }
+    if (split) {
+        hipLaunchKernelGGL(k_band_flags, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->n, c->sortedKeys, c->dp.rx,
+                           c->dp.xoff, c->dp.ownLo, c->dp.ownHi, bandLo, bandHi, c->wgBand, c->slabCounts + 2);
+        CHECK_LAUNCH(c);
+    }
     // SPH.cs:210-222 with the dead and the purely streaming stages folded together (bit-identical
     // results): CS_Clear is elided (density/pressure/acceleration are fully overwritten by the two
     // neighbour kernels; the force kernel zeroes the acceleration of the particles it skips), and
@@ -788,7 +833,26 @@ int sph_step_frame(sph_ctx* c, int sub_steps, float time_step) {
         if (last && tl >= 1) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
         if ((rc = dispatchKernel(c, SPH_K_DENSITY_PRESSURE))) return rc;
         if (last && tl >= 1) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
-        if ((rc = dispatchKernel(c, SPH_K_FORCE_XSPH, true))) return rc;
+        if (last && split) {
+            if ((rc = dispatchKernel(c, SPH_K_FORCE_XSPH, true, false, 1))) return rc;      // band workgroups
+            StateSet st = c->set[c->cur];
+            st.velV = c->set[1 - c->velCur].velV;                                           // what the force launch wrote
+            hipLaunchKernelGGL(k_slab_pack_final, dim3((c->n + kBlock * kKeepItems - 1) / (kBlock * kKeepItems)), dim3(kBlock), 0,
+                               c->stream, c->dp, st, c->ownedRef, (const uint8_t*)c->wgBand, 1, ap.leftBelow, ap.rightFrom,
+                               (SlabRecord*)ap.devL, ap.capL, (SlabRecord*)ap.devR, ap.capR, c->slabCounts);
+            CHECK_LAUNCH(c);
+        }
+        if (last && ap.armed) {   // counts + the frame's plane shift to the host; the host may wait for this point only
+            HIP_TRY(c, hipMemcpyAsync(c->hostInts + 10, c->slabCounts, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->hostInts + 8, c->counters + SPH_CTR_MAX_PLANE_SHIFT, sizeof(int), hipMemcpyDeviceToHost,
+                                      c->stream));
+            HIP_TRY(c, hipEventRecord(c->packEvent, c->stream));
+            c->packPending = true;
+            c->packCapL = ap.capL; c->packCapR = ap.capR;
+            c->bandValid = split;
+            c->bandSendLo = ap.leftBelow; c->bandSendHi = ap.rightFrom;
+        }
+        if ((rc = dispatchKernel(c, SPH_K_FORCE_XSPH, true, false, last && split ? 0 : -1))) return rc;
         if (last && tl >= 1) HIP_TRY(c, hipEventRecord(ev[4], c->stream));
         if ((rc = dispatchKernel(c, SPH_K_VV_FULL_STEP, true, last))) return rc;
         if (last && tl >= 2) {
@@ -830,6 +894,7 @@ int sph_read_counter(sph_ctx* c, int which, int* value) {
     if (which < 0 || which >= SPH_CTR_COUNT || !value) return fail(c, SPH_E_INVALID, "bad counter %d", which);
     HIP_TRY(c, hipSetDevice(c->device));
     if (which == SPH_CTR_MAX_PLANE_SHIFT && c->cachedShift >= 0) { *value = c->cachedShift; return SPH_OK; }
+    if (which == SPH_CTR_BAND_MISSES && c->cachedMisses >= 0) { *value = c->cachedMisses; return SPH_OK; }
     if (which == SPH_CTR_COLLISIONS) {
         if (int rcFold = foldCollisions(c)) return rcFold;
         if (c->collisionsResetPending) { *value = 0; return SPH_OK; }
@@ -1036,15 +1101,19 @@ int sph_slab_download(sph_ctx* c, sph_slab_record* records, int max_records, int
     if (!n_out || max_records < 0 || (max_records > 0 && !records)) return fail(c, SPH_E_INVALID, "bad arguments");
     HIP_TRY(c, hipSetDevice(c->device));
     *n_out = 0;
-    if (c->n == 0) return SPH_OK;
+    // between sph_slab_rebuild and the grid build the slots from filter.nOld on are records just received
+    // (copies of particles their senders still hold): not part of the local set yet
+    const int nLocal = c->filter.active ? c->filter.nOld : c->n;
+    if (nLocal == 0) return SPH_OK;
+    if (c->packPending) return fail(c, SPH_E_STATE, "collect the in-frame pack first (sph_slab_pack_wait)");
     if (c->haveParams) deriveParams(c);
-    c->dp.n = c->n;
-    int rc = ensureRecStage(c, (size_t)c->n);
+    c->dp.n = nLocal;
+    int rc = ensureRecStage(c, (size_t)nLocal);
     if (rc) return rc;
     HIP_TRY(c, hipMemsetAsync(c->slabCounts, 0, 4 * sizeof(int), c->stream));
-    hipLaunchKernelGGL(k_slab_export, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->dp, curSet(c),
+    hipLaunchKernelGGL(k_slab_export, dim3(blocksFor(nLocal)), dim3(kBlock), 0, c->stream, c->dp, curSet(c),
                        c->ownedRef, owned_only, c->recStage,
-                       c->n, c->slabCounts);
+                       nLocal, c->slabCounts);
     CHECK_LAUNCH(c);
     int cnt = 0;
     if (int rcRead = readInts(c, c->slabCounts, 1, &cnt)) return rcRead;
@@ -1107,10 +1176,43 @@ int sph_slab_rebuild(sph_ctx* c, int keep_lo, int keep_hi, const void* dev_from_
         hipLaunchKernelGGL(k_slab_append_at, dim3(blocksFor(n_from_right)), dim3(kBlock), 0, c->stream,
                            (const SlabRecord*)dev_from_right, n_from_right, cur, nOld + n_from_left, phaseCheck(c));
     CHECK_LAUNCH(c);
-    c->filter = SlabFilter{1, keep_lo, keep_hi, nOld, c->ownedRef};
+    c->filter = SlabFilter{1, keep_lo, keep_hi, nOld, c->ownedRef,
+                           c->bandValid ? (const uint8_t*)c->wgBand : (const uint8_t*)nullptr, c->bandSendLo, c->bandSendHi};
+    c->bandValid = false;
     c->n = nOld + n_from_left + n_from_right;
     c->gridValid = false; c->maskValid = false;
     *n_local = c->n;       // upper bound until the grid build; sph_particle_count afterwards
+    return SPH_OK;
+}
+
+int sph_slab_arm_pack(sph_ctx* c, int left_below, int right_from, int band_margin, void* dev_left, int cap_left,
+                      void* dev_right, int cap_right) {
+    if (!c) return SPH_E_INVALID;
+    if (!c->slab) return fail(c, SPH_E_STATE, "sph_slab_configure first");
+    if (band_margin < 0 || cap_left < 0 || cap_right < 0 || (cap_left > 0 && !dev_left) || (cap_right > 0 && !dev_right))
+        return fail(c, SPH_E_INVALID, "bad message buffers");
+    if (c->packPending) return fail(c, SPH_E_STATE, "the previous in-frame pack was not collected (sph_slab_pack_wait)");
+    c->armedPack.armed = true;
+    c->armedPack.leftBelow = left_below; c->armedPack.rightFrom = right_from; c->armedPack.margin = band_margin;
+    c->armedPack.devL = dev_left; c->armedPack.capL = cap_left;
+    c->armedPack.devR = dev_right; c->armedPack.capR = cap_right;
+    return SPH_OK;
+}
+
+int sph_slab_pack_wait(sph_ctx* c, int* n_left, int* n_right, int* n_band_workgroups) {
+    if (!c) return SPH_E_INVALID;
+    if (!n_left || !n_right) return fail(c, SPH_E_INVALID, "bad arguments");
+    if (!c->packPending) return fail(c, SPH_E_STATE, "no in-frame pack pending (sph_slab_arm_pack + sph_step_frame first)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventSynchronize(c->packEvent));
+    c->packPending = false;
+    c->cachedShift = c->hostInts[8];
+    *n_left = c->hostInts[10];
+    *n_right = c->hostInts[11];
+    if (n_band_workgroups) *n_band_workgroups = c->hostInts[12];
+    if (*n_left > c->packCapL || *n_right > c->packCapR)
+        return fail(c, SPH_E_NOMEM, "slab message overflow: %d/%d left, %d/%d right records", *n_left, c->packCapL, *n_right,
+                    c->packCapR);
     return SPH_OK;
 }
 

@@ -430,7 +430,9 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_rows(DevParams P, const f
                                                             const int* __restrict__ counters, int zeroDeadAcc) {
     __shared__ int queue[kHitQueue][kBlock];
     const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
-    const int s = xcd_tile(blockIdx.x, gridDim.x, P.xcdRun) * kBlock + threadIdx.x;
+    const int wg = xcd_tile(blockIdx.x, gridDim.x, P.xcdRun);
+    if (P.wgBand && P.wgBand[wg] != P.wgPhase) return;         // slab mode: the other launch of the pair does this one
+    const int s = wg * kBlock + threadIdx.x;
     const ForceSelf me = force_load_self(P, s, posM, velIn, rhoP);
     ForceAcc A{0.0f, P.gravity * me.densitySelf, 0.0f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // compute:219
     const int3 c = search_cell(P, me.p.x, me.p.y, me.p.z);
@@ -461,7 +463,9 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
     int (*const wordOf)[kBlock] = lds;                   // [kMaskWords]
     int (*const rowA)[kBlock] = lds + kMaskWords;        // [9] first slot of every row
     const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
-    const int s = xcd_tile(blockIdx.x, gridDim.x, P.xcdRun) * kBlock + threadIdx.x;
+    const int wg = xcd_tile(blockIdx.x, gridDim.x, P.xcdRun);
+    if (P.wgBand && P.wgBand[wg] != P.wgPhase) return;         // slab mode: the other launch of the pair does this one
+    const int s = wg * kBlock + threadIdx.x;
     const ForceSelf me = force_load_self(P, s, posM, velIn, rhoP);
     ForceAcc A{0.0f, P.gravity * me.densitySelf, 0.0f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // compute:219
     const int3 c = search_cell(P, me.p.x, me.p.y, me.p.z);

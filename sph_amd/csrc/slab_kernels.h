@@ -134,6 +134,99 @@ __global__ __launch_bounds__(kBlock) void k_slab_pack(DevParams P, StateSet st, 
     }
 }
 
+// ---- exchange overlapped with compute -------------------------------------------------------------------
+// The face messages need the END-of-frame state of the particles near a face, and feed the NEXT grid build.
+// To send them while the frame is still running, the last sub-step's CS_ForceXSPH is launched twice: first
+// the "band" workgroups (256 consecutive slots holding at least one owned particle binned within
+// ghost + margin planes of a face), then the rest.  Between the two, k_slab_pack_final computes the tail of
+// the frame (full step, boundary, damping) for the band particles IN REGISTERS and writes the records; the
+// state arrays are not touched, so the second force launch reads exactly what an unsplit launch reads, and
+// the ordinary tail kernel runs over everything afterwards (the band's tail is computed twice: cheap).
+__global__ __launch_bounds__(kBlock) void k_band_flags(int n, const uint32_t* __restrict__ sortedKeys, int rx, int xoff,
+                                                       int ownLo, int ownHi, int bandLo, int bandHi,
+                                                       uint8_t* __restrict__ wgBand, int* __restrict__ nBand) {
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    int band = 0;
+    if (s < n) {
+        const int plane = (int)(sortedKeys[s] % (uint32_t)rx);
+        const int g = plane + xoff;
+        band = plane >= ownLo && plane < ownHi && (g < bandLo || g >= bandHi);
+    }
+    band = __syncthreads_or(band);
+    if (threadIdx.x == 0) {
+        wgBand[blockIdx.x] = band ? 1 : 0;
+        if (band) atomicAdd(nBand, 1);      // statistic only (how much of the force kernel runs before the pack)
+    }
+}
+
+// state of slot s after the fused tail of the frame (k_full_bound_damp), computed without writing it
+__device__ __forceinline__ void final_state(const DevParams& P, const StateSet& st, int s, int damp, float4& p, float4& v) {
+    p = st.posM[s];
+    v = st.velV[s];
+    const float4 a = st.acc[s];
+    const float hdt = 0.5f * P.dt;
+    v.x += hdt * a.x; v.y += hdt * a.y; v.z += hdt * a.z;
+    (void)bound_obs_body(P, p, v);
+    if (damp) damp_velocity(v);
+}
+
+// k_slab_pack on the band workgroups, with the tail of the frame applied on the fly.  `st.velV` = the
+// velocities CS_ForceXSPH has just written.
+__global__ __launch_bounds__(kBlock) void k_slab_pack_final(DevParams P, StateSet st, OwnedRef owned,
+                                                            const uint8_t* __restrict__ wgBand, int damp, int leftBelow,
+                                                            int rightFrom, SlabRecord* __restrict__ left, int capLeft,
+                                                            SlabRecord* __restrict__ right, int capRight,
+                                                            int* __restrict__ counts) {
+    __shared__ int waveTot[2][kBlock / 64];
+    __shared__ int blockBase[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int first = blockIdx.x * (kBlock * kKeepItems) + threadIdx.x;
+    unsigned long long mL[kKeepItems], mR[kKeepItems];
+    int totL = 0, totR = 0;
+#pragma unroll
+    for (int it = 0; it < kKeepItems; it++) {
+        const int s = first + it * kBlock;
+        bool toL = false, toR = false;
+        if (s < P.n && wgBand[s >> 8] && was_owned(owned, s)) {     // wave-uniform: 64 | 256
+            float4 p, v;
+            final_state(P, st, s, damp, p, v);
+            const int g = global_plane(P, p.x);
+            toL = g < leftBelow;
+            toR = g >= rightFrom;
+        }
+        mL[it] = __ballot(toL);
+        mR[it] = __ballot(toR);
+        totL += __popcll(mL[it]);
+        totR += __popcll(mR[it]);
+    }
+    if (lane == 0) { waveTot[0][wave] = totL; waveTot[1][wave] = totR; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int t = (waveTot[threadIdx.x][0] + waveTot[threadIdx.x][1]) + (waveTot[threadIdx.x][2] + waveTot[threadIdx.x][3]);
+        blockBase[threadIdx.x] = t ? atomicAdd(&counts[threadIdx.x], t) : 0;
+    }
+    __syncthreads();
+    int kL = blockBase[0], kR = blockBase[1];
+    for (int w = 0; w < wave; w++) { kL += waveTot[0][w]; kR += waveTot[1][w]; }
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int it = 0; it < kKeepItems; it++) {
+        const int s = first + it * kBlock;
+        const bool l = (mL[it] >> lane) & 1ull, r = (mR[it] >> lane) & 1ull;
+        if (l || r) {
+            SlabRecord rec = make_record(st, s);
+            float4 p, v;
+            final_state(P, st, s, damp, p, v);
+            rec.posM = p;
+            rec.velV = v;
+            if (l) { const int d = kL + __popcll(mL[it] & below); if (d < capLeft) left[d] = rec; }
+            if (r) { const int d = kR + __popcll(mR[it] & below); if (d < capRight) right[d] = rec; }
+        }
+        kL += __popcll(mL[it]);
+        kR += __popcll(mR[it]);
+    }
+}
+
 // Received records become source slots base .. base+nrec-1 of the current set; which of them (and of
 // the old slots) survive is decided by the next grid build (SlabFilter in k_hash_count).
 __global__ __launch_bounds__(kBlock) void k_slab_append_at(const SlabRecord* __restrict__ rec, int nrec, StateSet dst,

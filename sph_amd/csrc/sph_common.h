@@ -38,6 +38,10 @@ struct DevParams {
     int   obb;        // length(_BoundaryHalfExtents) > 0.001f  (compute:349)
     // derived once on the host in fp32 (ORACLE rule O4)
     float h2, poly6, spikyGradFactor, viscLapFactor, lapColFactor;
+    // slab mode, exchange overlapped with compute: workgroup wg of CS_ForceXSPH runs only if
+    // wgBand[wg] == wgPhase (null: every workgroup runs)
+    const uint8_t* wgBand;
+    int   wgPhase;
 };
 
 // ---- memory order of the cells ("row tiles") --------------------------------------------------------

@@ -115,11 +115,21 @@ class DevicePort:
         nl, nr = self.e.slab_pack(left_below, right_from, self.send_l.data_ptr(), self.cap, self.send_r.data_ptr(), self.cap)
         return self.send_l[:nl], self.send_r[:nr]
 
+    def arm_pack(self, left_below, right_from, band_margin):
+        """The next step_frame packs its own face messages, early (sph_slab_arm_pack)."""
+        self.e.slab_arm_pack(left_below, right_from, band_margin, self.send_l.data_ptr(), self.cap, self.send_r.data_ptr(), self.cap)
+
+    def pack_wait(self):
+        nl, nr = self.e.slab_pack_wait()
+        return self.send_l[:nl], self.send_r[:nr]
+
     def rebuild(self, keep_lo, keep_hi, from_left, from_right):
         pl = from_left.data_ptr() if from_left is not None and from_left.shape[0] else None
         pr = from_right.data_ptr() if from_right is not None and from_right.shape[0] else None
         if pl is not None or pr is not None:
-            self.torch.cuda.synchronize(self.device)      # received data is complete
+            # received data is complete (torch's stream only: the engine's own stream may still be running the
+            # frame whose messages these are -- that is the overlap)
+            self.torch.cuda.current_stream(self.device).synchronize()
         nl = 0 if pl is None else from_left.shape[0]
         nr = 0 if pr is None else from_right.shape[0]
         return self.e.slab_rebuild(keep_lo, keep_hi, pl, nl, pr, nr)
@@ -240,7 +250,7 @@ class SlabEngine:
 
     def __init__(self, port, comm: NeighbourComm, rank: int, world: int, ghost_planes: int = 8,
                  capacity_factor: float = 1.6, rebalance_every: int = 0, max_cut_shift: Optional[int] = None,
-                 rebalance_threshold: float = 1.05):
+                 rebalance_threshold: float = 1.05, overlap: bool = False):
         self.port, self.comm, self.rank, self.world = port, comm, rank, world
         self.ghost = int(ghost_planes)
         self.capacity_factor = capacity_factor
@@ -250,6 +260,15 @@ class SlabEngine:
         self.cuts = None
         self.recuts = 0
         self.imbalance = 1.0
+        # overlap: a frame packs its own face messages between the two launches of its last force kernel, and the
+        # exchange for the NEXT frame runs while the rest of the frame is still on the GPU (sph_slab_arm_pack)
+        self.overlap = bool(overlap)
+        if self.overlap and self.rebalance_every:
+            raise ValueError("overlap and moving cuts are not combined yet")
+        self.band_margin = max(self.ghost // 2, 1)     # planes a particle may move per frame under the halo condition
+        self.band_misses = 0
+        self.band_fraction = 0.0       # share of the last force kernel that ran before the pack
+        self._primed = False
         self.e = port.e
         self.n_global = 0
         self.n = 0
@@ -404,11 +423,39 @@ class SlabEngine:
             self.n = self.port.local_count()
             self.e.n = self.n
 
+    def _send_range(self):
+        x0, x1 = self.own
+        return (x0 + self.ghost if self.rank > 0 else 0,
+                x1 - self.ghost if self.rank < self.world - 1 else self.grid[0])
+
     def step_frame(self, sub_steps, time_step):
         self.sub_steps = int(sub_steps)
-        self.exchange()
-        self.e.step_frame(sub_steps, time_step)
+        if not (self.overlap and self.world > 1):
+            self.exchange()
+            self.e.step_frame(sub_steps, time_step)
+            self._refresh_count()
+            self.frames += 1
+            return
+        # overlapped: frame f's messages are packed inside frame f and travel while its second half runs
+        if not self._primed:
+            self.exchange()                         # the very first frame needs its ghosts the classic way
+            self._primed = True
+        left_below, right_from = self._send_range()
+        self.port.arm_pack(left_below, right_from, self.band_margin)
+        self.e.step_frame(sub_steps, time_step)     # returns once everything is enqueued (one sync: survivor count)
         self._refresh_count()
+        if self.frames > 0:
+            self.band_misses += self.e.read_counter(abi.CTR_BAND_MISSES)    # cached by the build: no sync
+        t0 = time.perf_counter()
+        to_l, to_r = self.port.pack_wait()          # the band part of the frame is done; the GPU carries on
+        self.band_fraction = getattr(self.e, "band_workgroups", 0) / max((self.n + 255) // 256, 1)
+        shift = self.e.read_counter(abi.CTR_MAX_PLANE_SHIFT)
+        if 2 * self.sub_steps * (1 + shift) > self.ghost:
+            self.halo_violations += 1
+        from_l, from_r = self.comm.exchange(to_l, to_r)
+        self.n = self.port.rebuild(self.keep[0], self.keep[1], from_l, from_r)   # enqueued behind the frame
+        self.e.n = self.n
+        self.exchange_s += time.perf_counter() - t0
         self.frames += 1
 
     def dispatch(self, kernel_id, count):
@@ -480,8 +527,11 @@ def bench_main(args, rank, local_rank, world):
                          msg_capacity=max(per_gpu // 4, 65536))
     # config 5 starts balanced and stays so (G equal blocks side by side); SPH_BENCH_REBALANCE=K re-cuts the
     # slabs by particle count every K frames anyway (0 = static cuts)
-    se = SlabEngine(port, comm, rank, world, ghost_planes=8,
-                    rebalance_every=int(os.environ.get("SPH_BENCH_REBALANCE", "0")))
+    # SPH_BENCH_OVERLAP=0: classic order (pack after the frame, exchange before the next one) instead of the
+    # in-frame pack whose exchange runs under the second half of the frame
+    rebalance = int(os.environ.get("SPH_BENCH_REBALANCE", "0"))
+    overlap = os.environ.get("SPH_BENCH_OVERLAP", "1") != "0" and not rebalance
+    se = SlabEngine(port, comm, rank, world, ghost_planes=8, rebalance_every=rebalance, overlap=overlap)
     sc = scenes.config5(se, gpus=world, per_gpu=per_gpu)
     sc.sph.use_step_frame = True
     sc.start()
@@ -508,6 +558,7 @@ def bench_main(args, rank, local_rank, world):
     tm = eng.get_timings()
     n_total = sc.sph.particleCount       # conservation is asserted by tests/test_slab_*.py
     viol = comm.allreduce_sum(se.halo_violations)
+    misses = comm.allreduce_sum(se.band_misses)
     overflow = comm.allreduce_sum(eng.read_counter(abi.CTR_BIN_OVERFLOW))
     force_ms = comm.allreduce_max(tm["force_ms"])
     # The same per-GPU load on ONE GPU, no slabs (every rank runs it on its own GPU, concurrently): what
@@ -541,6 +592,8 @@ def bench_main(args, rank, local_rank, world):
                        "particles": n_total, "sub_steps": sub, "parallelism": f"slab{world}",
                        "halo_violations": viol, "bin_overflow_cells": overflow,
                        "rebalance_every": se.rebalance_every, "recuts": se.recuts,
+                       "exchange_overlapped": se.overlap, "band_fraction_rank0": round(se.band_fraction, 4),
+                       "band_misses": misses,
                        "exchange_ms_per_step_rank0": se.exchange_s / args.steps * 1e3,
                        "one_gpu_same_load": None if solo is None else {
                            "value": solo, "workload": f"config5, {per_gpu} particles, one GPU, no slabs (slowest of the "

@@ -35,6 +35,8 @@ class _Shim:
     def read_counter(self, which=0):
         if which == abi.CTR_MAX_PLANE_SHIFT:
             return self._p.max_shift
+        if which == abi.CTR_BAND_MISSES:
+            return 0
         return self._p.ora.read_counter(which)
 
 
@@ -45,6 +47,7 @@ class OraclePort:
         self.device = torch.device("cpu")
         self.ids = np.zeros(0, np.uint32)          # global id of local particle k
         self.owned_mask = None                     # owned at the last grid build (None = all)
+        self.carry_owned = None                    # after a rebuild: ids that were owned before it (received records are not)
         self.max_shift = 0
 
     def configure(self, rx_global, x_offset, rx_local, ry, rz, cap, own_lo, own_hi, capacity):
@@ -78,6 +81,7 @@ class OraclePort:
 
     def upload_owned(self, records):
         self._set_local(np.array(records, copy=True))
+        self.carry_owned = None
 
     def _planes(self, x, p):
         c = np.floor(((x - np.float32(p.minBound[0])) / np.float32(p.cellSize)).astype(np.float32)).astype(np.int64)
@@ -90,7 +94,12 @@ class OraclePort:
         aos = self.ora.download_particles()
         recs = abi.records_from_aos(aos, self.ids)
         valid = self.ids != 0xFFFFFFFF
-        owned = valid if self.owned_mask is None else (self.owned_mask & valid)
+        if self.owned_mask is not None:
+            owned = self.owned_mask & valid
+        elif self.carry_owned is not None:         # rebuilt, not stepped yet: what the engine's slab_download reports
+            owned = valid & np.isin(self.ids, self.carry_owned)
+        else:
+            owned = valid
         return recs, owned, self._planes(aos[:, 0], self.params)
 
     def pack(self, left_below, right_from):
@@ -100,15 +109,24 @@ class OraclePort:
         return (torch.from_numpy(to_l.view(np.uint8).reshape(-1, REC).copy()),
                 torch.from_numpy(to_r.view(np.uint8).reshape(-1, REC).copy()))
 
+    def arm_pack(self, left_below, right_from, band_margin):
+        self._armed = (left_below, right_from)
+
+    def pack_wait(self):
+        return self.pack(*self._armed)              # the oracle ran the whole frame: nothing to overlap with
+
     def rebuild(self, keep_lo, keep_hi, from_left, from_right):
         recs, owned, plane = self._current()
         parts = [recs[owned & (plane >= keep_lo) & (plane < keep_hi)]]
+        carry = recs["id"][owned].copy()
         for t in (from_left, from_right):
             if t is not None and t.shape[0]:
                 r = np.frombuffer(t.contiguous().numpy().tobytes(), dtype=abi.SLAB_RECORD_DTYPE)
                 pl = self._planes(r["pos"][:, 0], self.params)
                 parts.append(r[(pl >= keep_lo) & (pl < keep_hi)])
-        return self._set_local(np.concatenate(parts))
+        n = self._set_local(np.concatenate(parts))
+        self.carry_owned = carry
+        return n
 
     def after_build(self):
         aos = self.ora.download_particles()

@@ -38,7 +38,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, frames, out_dir, step_frame, ghost=8, rebalance_every=0, sub_steps=1):
+def _worker(rank, world, port, frames, out_dir, step_frame, ghost=8, rebalance_every=0, sub_steps=1, overlap=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -47,7 +47,7 @@ def _worker(rank, world, port, frames, out_dir, step_frame, ghost=8, rebalance_e
     oport = OraclePort(Oracle())
     comm = slab.NeighbourComm(rank, world, torch.device("cpu"), backend="gloo")
     se = slab.SlabEngine(oport, comm, rank, world, ghost_planes=ghost, rebalance_every=rebalance_every,
-                         max_cut_shift=4, rebalance_threshold=1.0)
+                         max_cut_shift=4, rebalance_threshold=1.0, overlap=overlap)
     orig = se.set_params
 
     def set_params(p):
@@ -108,6 +108,25 @@ def test_two_sub_steps_two_slabs_equal_single_domain(tmp_path, oracle_built, ste
     got = abi.aos_from_records(recs[np.argsort(recs["id"])])
     for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
         assert np.array_equal(got[:, sl], want[:, sl]), "two sub-steps: slab run differs from the single-domain run"
+
+
+def test_overlapped_driver_equals_single_domain(tmp_path, oracle_built):
+    """The overlap protocol of the driver (first frame classic, then arm -> step -> pack_wait -> exchange -> rebuild at
+    the END of every frame) on oracle ports: same particles, same results."""
+    frames = 6
+    from oracle.ora import Oracle
+    ref = Oracle()
+    sc = small_tank(ref)
+    sc.run(frames)
+    want = ref.download_particles()
+    n = want.shape[0]
+    mp.spawn(_worker, args=(3, _free_port(), frames, str(tmp_path), True, 4, 0, 1, True), nprocs=3, join=True)
+    recs = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(3)])
+    assert np.load(tmp_path / "counts0.npy").tolist() == [n] * frames
+    assert np.array_equal(np.sort(recs["id"]), np.arange(n, dtype=np.uint32))
+    got = abi.aos_from_records(recs[np.argsort(recs["id"])])
+    for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
+        assert np.array_equal(got[:, sl], want[:, sl]), "overlapped slab run differs from the single-domain run"
 
 
 @pytest.mark.parametrize("world", [2, 3])

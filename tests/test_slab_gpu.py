@@ -15,7 +15,23 @@ from tests.test_slab_gloo import _free_port, small_tank
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, frames, out_dir, n, ghost, drop_phases, rebalance_every=0, sub_steps=1):
+def long_tank(engine, n=0, sub_steps=1):
+    """640 x 4 x 1 units (2560 x 16 x 4 cells) with two thin bars of fluid 600 units long: even after the bars have
+    spread over a few dozen cell rows, a rank's part of a row is several workgroups long, so the workgroups near a
+    slab face are a small part of all."""
+    from sph_amd import scenes
+    from sph_amd.host import SPH, Scene, SpawnBox, Time, Transform
+    cube = Transform(position=(0, 2, 0), localScale=(640, 4, 1))
+    boxes = [SpawnBox(48000, (600.0, 0.5, 0.45), 20, 0.1, 0.2, position=(0, 2.75, 0.0)),
+             SpawnBox(24000, (600.0, 0.25, 0.45), 10, 0.1, 0.2, position=(0, 1.125, 0.0))]
+    f = dict(scenes.SCENE_COMMON)
+    f.update(gridResolution=4, subSteps=sub_steps)
+    sph = SPH(engine, **f, surfaceTensionCoefficient=0.01, xsphEpsilon=0.2, boundaryCube=cube, spawnBoxes=boxes)
+    return Scene(sph, Time(), [])
+
+
+def _worker(rank, world, port, frames, out_dir, n, ghost, drop_phases, rebalance_every=0, sub_steps=1, overlap=False,
+            tank="small"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -23,14 +39,14 @@ def _worker(rank, world, port, frames, out_dir, n, ghost, drop_phases, rebalance
     dport = slab.DevicePort(eng, 0, msg_capacity=n)
     comm = slab.NeighbourComm(rank, world, torch.device("cuda", 0), backend="gloo")
     se = slab.SlabEngine(dport, comm, rank, world, ghost_planes=ghost, rebalance_every=rebalance_every,
-                         max_cut_shift=4, rebalance_threshold=1.0)
+                         max_cut_shift=4, rebalance_threshold=1.0, overlap=overlap)
     if drop_phases:
         # records arrive without their spawn-box index: the second box's mass / viscosity / rest density
         # then disagree with row 0 of the phase table, and the engine has to notice (PhaseCheck) and
         # keep gathering mass and viscosity per particle
         add = se.add_rows
         se.add_rows = lambda first_id, rows, phase=0: add(first_id, rows, 0)
-    sc = small_tank(se, n=n, sub_steps=sub_steps)
+    sc = (long_tank if tank == "long" else small_tank)(se, n=n, sub_steps=sub_steps)
     sc.sph.use_step_frame = True
     sc.start()
     counts = []
@@ -38,8 +54,9 @@ def _worker(rank, world, port, frames, out_dir, n, ghost, drop_phases, rebalance
         sc.frame()
         counts.append(se.count_global())
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), se.owned_records())
-    np.save(os.path.join(out_dir, f"meta{rank}.npy"), np.array(counts + [se.halo_violations]))
+    np.save(os.path.join(out_dir, f"meta{rank}.npy"), np.array(counts + [se.halo_violations + se.band_misses]))
     np.save(os.path.join(out_dir, f"cuts{rank}.npy"), np.array(se.cuts + [se.recuts]))
+    np.save(os.path.join(out_dir, f"band{rank}.npy"), np.array([se.band_fraction]))
     eng.destroy()
     dist.destroy_process_group()
 
@@ -111,6 +128,55 @@ def test_two_sub_steps_two_slabs_bitwise(tmp_path):
     got = abi.aos_from_records(recs[np.argsort(recs["id"])])
     for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
         assert np.array_equal(got[:, sl], want[:, sl]), "two sub-steps: 2 slabs differ from one engine"
+
+
+@pytest.mark.parametrize("world,ghost,sub_steps,drop_phases", [(2, 8, 1, False), (3, 8, 1, False), (6, 4, 1, False),
+                                                                (2, 8, 2, False), (2, 8, 1, True)])
+def test_overlapped_exchange_bitwise(tmp_path, world, ghost, sub_steps, drop_phases):
+    """sph_slab_arm_pack: every frame packs its own face messages between the two launches of its last force kernel
+    (band workgroups first) and the exchange runs while the rest of the frame is still on the GPU.  Same results as
+    one engine, bit for bit; no particle missed by the band (SPH_CTR_BAND_MISSES)."""
+    frames, n = 8, 3000
+    eng = abi.Engine(0)
+    sc = small_tank(eng, n=n, sub_steps=sub_steps)
+    sc.sph.use_step_frame = True
+    sc.run(frames)
+    want = eng.download_particles()
+    eng.destroy()
+    n = want.shape[0]
+    mp.spawn(_worker, args=(world, _free_port(), frames, str(tmp_path), n, ghost, drop_phases, 0, sub_steps, True),
+             nprocs=world, join=True)
+    recs = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)])
+    meta = np.load(tmp_path / "meta0.npy")
+    assert meta[:-1].tolist() == [n] * frames, "particles not conserved across slabs"
+    assert meta[-1] == 0, "halo violations or particles missed by the band"
+    assert np.array_equal(np.sort(recs["id"]), np.arange(n, dtype=np.uint32))
+    got = abi.aos_from_records(recs[np.argsort(recs["id"])])
+    for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
+        assert np.array_equal(got[:, sl], want[:, sl]), f"{world} overlapped slabs differ from one engine"
+
+
+def test_overlapped_exchange_really_splits_the_force_kernel(tmp_path):
+    """A tank with long, dense cell rows: only the workgroups near the slab faces run before the pack (band_fraction
+    well below 1), the rest after it -- and the result is still one engine's, bit for bit."""
+    frames, world = 6, 2
+    eng = abi.Engine(0)
+    sc = long_tank(eng)
+    sc.sph.use_step_frame = True
+    sc.run(frames)
+    want = eng.download_particles()
+    assert eng.read_counter(abi.CTR_BIN_OVERFLOW) == 0
+    eng.destroy()
+    n = want.shape[0]
+    mp.spawn(_worker, args=(world, _free_port(), frames, str(tmp_path), n, 12, False, 0, 1, True, "long"), nprocs=world, join=True)
+    recs = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)])
+    meta = np.load(tmp_path / "meta0.npy")
+    band = [float(np.load(tmp_path / f"band{r}.npy")[0]) for r in range(world)]
+    assert all(0.0 < b < 0.6 for b in band), f"band fractions {band}: the force kernel was not really split"
+    assert meta[:-1].tolist() == [n] * frames and meta[-1] == 0, meta
+    got = abi.aos_from_records(recs[np.argsort(recs["id"])])
+    for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
+        assert np.array_equal(got[:, sl], want[:, sl]), "split force kernel: slabs differ from one engine"
 
 
 def test_plane_counts_equal_download():
