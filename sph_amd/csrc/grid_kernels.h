@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void k_rank_move(const uint32_t* __restrict
                                                       const uint32_t* __restrict__ perm,
                                                       const uint32_t* __restrict__ sid, int n, int cap, float dt,
                                                       const int* __restrict__ cellCum, StateSet src, StateSet dst,
-                                                      int* __restrict__ counters) {
+                                                      int* __restrict__ counters, float* __restrict__ pos3) {
     int k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= n) return;
     const uint32_t c = sortedKeys[k];
@@ -238,6 +238,8 @@ __global__ __launch_bounds__(kBlock) void k_rank_move(const uint32_t* __restrict
         const float hdt = 0.5f * dt;
         v.x += hdt * acc.x; v.y += hdt * acc.y; v.z += hdt * acc.z;
         p.x += v.x * dt; p.y += v.y * dt; p.z += v.z * dt;
+        // positions alone, 12 bytes per slot: what the density kernel's candidate loads read (physics_kernels.h)
+        if (pos3) { pos3[3 * d] = p.x; pos3[3 * d + 1] = p.y; pos3[3 * d + 2] = p.z; }
     } else {
         dst.acc[d] = src.acc[s];
         dst.rhoP[d] = src.rhoP[s];

@@ -104,6 +104,10 @@ struct sph_ctx {
     int bandSendLo = 0, bandSendHi = 0;
     int* planeCounts = nullptr; int planeCountsCap = 0;   // sph_slab_plane_counts
     int cachedShift = -1;             // SPH_CTR_MAX_PLANE_SHIFT as read along with sph_slab_pack's counts (-1 = not cached)
+    float* pos3 = nullptr;            // x, y, z per slot (12 bytes): candidate positions of the density kernel's fast path
+    bool pos3Valid = false;           // written by the half step that produced the current positions
+    bool slabMismatchClean = false;   // slab mode: phaseMismatch was read as 0 at the last grid build (covers this frame's records)
+    bool uniformMassOk = true;        // SPH_HIP_UNIFORM_MASS=0 switches the 12-byte candidate path off (A/B)
     int cachedMisses = -1;            // SPH_CTR_BAND_MISSES as read along with the survivor count of a slab build
     bool slabPackedOff = false;       // the phase table changed after the records were uploaded
     SlabRecord* recStage = nullptr;   // device staging for slab upload / download
@@ -172,7 +176,7 @@ void freeParticles(sph_ctx* c) {
         devFree(c->keys[k]); devFree(c->vals[k]);
     }
     devFree(c->color); devFree(c->phaseOfId); devFree(c->sid);
-    devFree(c->aosStage); devFree(c->recStage); devFree(c->planeCounts); c->planeCountsCap = 0; devFree(c->wgBand); devFree(c->blockInts); devFree(c->blockCollide); devFree(c->hitMask); devFree(c->nbrA); devFree(c->nbrB);
+    devFree(c->aosStage); devFree(c->recStage); devFree(c->planeCounts); c->planeCountsCap = 0; devFree(c->wgBand); devFree(c->blockInts); devFree(c->blockCollide); devFree(c->hitMask); devFree(c->nbrA); devFree(c->nbrB); devFree(c->pos3);
     c->recStageCap = 0;
     if (c->pinned) (void)hipHostFree(c->pinned);
     c->pinned = nullptr; c->pinnedBytes = 0;
@@ -341,6 +345,7 @@ int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
     if (rc) return rc;
     const SlabFilter filter = c->filter;
     c->filter.active = 0;
+    c->slabMismatchClean = false;
     if (c->slab) c->ownedRef = OwnedRef{c->keys[1], c->dp.rx, c->dp.ownLo, c->dp.ownHi};   // as of THIS build
     if (n == 0) {   // an empty slab: the zeroed table is its grid
         c->gridValid = true;
@@ -371,9 +376,11 @@ int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
         if (filter.bandWg)
             HIP_TRY(c, hipMemcpyAsync(c->hostInts + 1, c->counters + SPH_CTR_BAND_MISSES, sizeof(int), hipMemcpyDeviceToHost,
                                       c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->hostInts + 2, c->phaseMismatch, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         nNew = c->hostInts[0];
         c->cachedMisses = filter.bandWg ? c->hostInts[1] : 0;
+        c->slabMismatchClean = c->hostInts[2] == 0;   // every record of this frame has been checked by now (same stream)
         c->n = nNew;
         c->dp.n = nNew;
         if (nNew == 0) { c->cur = 1 - c->cur; c->velCur = 1 - c->velCur; c->gridValid = true; return SPH_OK; }
@@ -384,11 +391,12 @@ int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
     dst.velV = c->set[1 - c->velCur].velV;
     if (fuseHalfStep)   // sph_step_frame: rank + reorder + first CS_VvHalfStep in one pass
         hipLaunchKernelGGL(k_rank_move<true>, dim3(nbNew), dim3(kBlock), 0, c->stream, c->sortedKeys, perm, c->sid, nNew, c->cap,
-                           c->dp.dt, c->cellCum, src, dst, c->counters);
+                           c->dp.dt, c->cellCum, src, dst, c->counters, c->pos3);
     else
         hipLaunchKernelGGL(k_rank_move<false>, dim3(nbNew), dim3(kBlock), 0, c->stream, c->sortedKeys, perm, c->sid, nNew, c->cap,
-                           c->dp.dt, c->cellCum, src, dst, c->counters);
+                           c->dp.dt, c->cellCum, src, dst, c->counters, (float*)nullptr);
     CHECK_LAUNCH(c);
+    c->pos3Valid = fuseHalfStep;
     c->cur = 1 - c->cur;
     c->velCur = 1 - c->velCur;
     c->gridValid = true;
@@ -436,9 +444,20 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
                                 (c->slab ? (s.phase != nullptr && !c->slabPackedOff) : (c->havePhaseIds && !c->staticDirty));
             PackedNbr nbr{packed ? c->nbrA : nullptr, c->nbrB, s.velV, s.origId, c->phaseOfId,
                           c->slab ? (const uint8_t*)s.phase : (const uint8_t*)nullptr};
-            hipLaunchKernelGGL(k_density_pressure_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.rho0,
-                               s.rhoP, c->cellCum, c->counters, c->useHitMask ? c->hitMask : (uint32_t*)nullptr, c->capacity, nbr,
-                               c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr, c->blockInts);
+            // same particle mass in every phase, every particle's mass is its phase's (`packed`), and the 12-byte
+            // positions were written by the half step that produced the current positions: 12-byte candidates
+            bool uniform = packed && c->pos3 && c->pos3Valid && c->uniformMassOk && (!c->slab || c->slabMismatchClean);
+            for (size_t k = 1; uniform && k < c->phaseTable.size(); k++) uniform = c->phaseTable[k].mass == c->phaseTable[0].mass;
+            uint32_t* const mask = c->useHitMask ? c->hitMask : (uint32_t*)nullptr;
+            const uint32_t* const skeys = c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr;
+            if (uniform)
+                hipLaunchKernelGGL(k_density_pressure_rows<true>, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.rho0,
+                                   s.rhoP, c->cellCum, c->counters, mask, c->capacity, nbr, skeys, c->blockInts,
+                                   (const float*)c->pos3, c->phaseTable[0].mass);
+            else
+                hipLaunchKernelGGL(k_density_pressure_rows<false>, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.rho0,
+                                   s.rhoP, c->cellCum, c->counters, mask, c->capacity, nbr, skeys, c->blockInts,
+                                   (const float*)nullptr, 0.0f);
             if (c->slab)
                 hipLaunchKernelGGL(k_slab_shift_reduce, dim3(1), dim3(kBlock), 0, c->stream, c->blockInts, nb,
                                    c->counters + SPH_CTR_MAX_PLANE_SHIFT);
@@ -480,11 +499,13 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
         }
         case SPH_K_VV_HALF_STEP:
             c->maskValid = false;   // positions move
-            hipLaunchKernelGGL(k_half_step, dim3(nb), dim3(kBlock), 0, c->stream, n, c->dp.dt, s.posM, s.velV, s.acc);
+            hipLaunchKernelGGL(k_half_step, dim3(nb), dim3(kBlock), 0, c->stream, n, c->dp.dt, s.posM, s.velV, s.acc, c->pos3);
+            c->pos3Valid = c->pos3 != nullptr;
             break;
         case SPH_K_VV_FULL_STEP:
             if (fused) {   // + CS_BoundObs (+ CS_VelocityDamping after the last sub-step), one pass
                 c->maskValid = false;
+                c->pos3Valid = false;
                 if (int rcFold = foldCollisions(c)) return rcFold;
                 hipLaunchKernelGGL(k_full_bound_damp, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, s.acc,
                                    c->blockCollide, c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr,
@@ -496,6 +517,7 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
             break;
         case SPH_K_BOUND_OBS:
             c->maskValid = false;
+            c->pos3Valid = false;
             if (int rcFold = foldCollisions(c)) return rcFold;
             hipLaunchKernelGGL(k_bound_obs, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, c->blockCollide,
                                c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr);
@@ -532,6 +554,7 @@ int sph_create(sph_ctx** out, int device_id) {
     if (const char* hm = getenv("SPH_HIP_HITMASK")) c->useHitMask = atoi(hm) != 0;
     if (const char* xr = getenv("SPH_HIP_XCD_RUN")) c->xcdRunOverride = atoi(xr);
     if (const char* dbg = getenv("SPH_HIP_DEBUG")) c->debug = atoi(dbg) != 0;
+    if (const char* um = getenv("SPH_HIP_UNIFORM_MASS")) c->uniformMassOk = atoi(um) != 0;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return SPH_E_HIP;
@@ -598,6 +621,7 @@ static int allocCapacity(sph_ctx* c, int n) {
     if (!rc) rc = devAlloc(c, &c->hitMask, (size_t)n * kMaskWords);
     if (!rc) rc = devAlloc(c, &c->nbrA, (size_t)n);
     if (!rc) rc = devAlloc(c, &c->nbrB, (size_t)n);
+    if (!rc) rc = devAlloc(c, &c->pos3, 3 * ((size_t)n + kSlotPad));
     if (!rc) rc = devAlloc(c, &c->aosStage, (size_t)n * SPH_PARTICLE_FLOATS);
     if (rc) { freeParticles(c); return rc; }
     c->capacity = n;

@@ -112,6 +112,15 @@ struct PhaseConsts { float m0, m1, m2, m3, v0, v1, v2, v3; };   // named, not ar
 
 // CS_DensityPressure (compute:142-193), fast path.  Same operations in the same order as the
 // per-cell kernel below, so the density is bit-identical to the oracle's.
+// UNIFORM_MASS: every phase has the same particle mass (true of all the reference's scenes: 0.2) and every
+// particle's mass is its phase's (the conditions of the packed neighbour records), so a candidate is its position
+// only, read from `pos3` -- 12 bytes per slot, written by the kernel that did the half step -- instead of the
+// 16-byte posM entry: four candidates are 48 contiguous bytes per lane instead of 64, and the kernel is bound by
+// the lines its gathers touch.  (Loading 12 of the 16 bytes of posM entries gains nothing: same lines.)  In slab
+// mode the host takes this path only after it has read the sticky phaseMismatch flag as clean for this frame's
+// records (with the survivor count of the grid build).
+struct __attribute__((packed, aligned(4))) Float4U { float x, y, z, w; };   // 16-byte load from a 4-byte aligned address
+template <bool UNIFORM_MASS>
 __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, const float4* __restrict__ posM,
                                                                   const float* __restrict__ rho0,
                                                                   float2* __restrict__ rhoP,
@@ -120,7 +129,8 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
                                                                   uint32_t* __restrict__ hitMask, int maskStride,
                                                                   PackedNbr nbr,
                                                                   const uint32_t* __restrict__ slabKeys,
-                                                                  int* __restrict__ slabShift) {
+                                                                  int* __restrict__ slabShift,
+                                                                  const float* __restrict__ pos3, float uniformMass) {
     const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
     const int nRanges = capped ? 27 : 9;
     const int s = xcd_tile(blockIdx.x, gridDim.x, P.xcdRun) * kBlock + threadIdx.x;
@@ -169,6 +179,9 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
     // (Packed v_pk_*_f32 arithmetic was tried here: on gfx950 a packed op issues at half the rate
     // of a plain one -- scripts/experiments/valu_rate.hip -- so it only adds register shuffles; the
     // TU is built with -fno-slp-vectorize for the same reason.)
+    // compile-time: a wave-uniform RUN-TIME choice between the two candidate loads inside the loop (slab mode's
+    // phaseMismatch flag, as the force kernel reads it) cost 0.24 instead of 0.13 ms; the host decides instead
+    constexpr bool uniform = UNIFORM_MASS;
     RowRange r = range_at(P, cellCum, c, 0, capped, true);
 #pragma unroll 1
     for (int t = 0; t < nRanges; t++) {
@@ -178,10 +191,16 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
             // one 32-bit byte offset + immediates: slots past the row's end are loaded (the arrays
             // are padded by kSlotPad entries) and rejected by the predicates below
             const char* const qb = (const char*)posM + ((uint32_t)j << 4);
-            const float4 q0 = *(const float4*)qb;
-            const float4 q1 = *(const float4*)(qb + 16);
-            const float4 q2 = *(const float4*)(qb + 32);
-            const float4 q3 = *(const float4*)(qb + 48);
+            float4 q0, q1, q2, q3;
+            if (UNIFORM_MASS && uniform) {
+                const char* const tb = (const char*)pos3 + (uint32_t)j * 12u;
+                const Float4U c0 = *(const Float4U*)tb, c1 = *(const Float4U*)(tb + 16), c2 = *(const Float4U*)(tb + 32);
+                q0 = make_float4(c0.x, c0.y, c0.z, uniformMass); q1 = make_float4(c0.w, c1.x, c1.y, uniformMass);
+                q2 = make_float4(c1.z, c1.w, c2.x, uniformMass); q3 = make_float4(c2.y, c2.z, c2.w, uniformMass);
+            } else {
+                q0 = *(const float4*)qb; q1 = *(const float4*)(qb + 16);
+                q2 = *(const float4*)(qb + 32); q3 = *(const float4*)(qb + 48);
+            }
             const float rs0 = dist2_exact(p.x - q0.x, p.y - q0.y, p.z - q0.z);
             const float rs1 = dist2_exact(p.x - q1.x, p.y - q1.y, p.z - q1.z);
             const float rs2 = dist2_exact(p.x - q2.x, p.y - q2.y, p.z - q2.z);
@@ -577,7 +596,8 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
 
 // CS_VvHalfStep (compute:309-319)
 __global__ __launch_bounds__(kBlock) void k_half_step(int n, float dt, float4* __restrict__ posM,
-                                                      float4* __restrict__ velV, const float4* __restrict__ acc) {
+                                                      float4* __restrict__ velV, const float4* __restrict__ acc,
+                                                      float* __restrict__ pos3) {
     int s = blockIdx.x * kBlock + threadIdx.x;
     if (s >= n) return;
     float4 p = posM[s], v = velV[s];
@@ -587,6 +607,7 @@ __global__ __launch_bounds__(kBlock) void k_half_step(int n, float dt, float4* _
     p.x += v.x * dt; p.y += v.y * dt; p.z += v.z * dt;
     velV[s] = v;
     posM[s] = p;
+    if (pos3) { pos3[3 * s] = p.x; pos3[3 * s + 1] = p.y; pos3[3 * s + 2] = p.z; }   // see k_density_pressure_rows
 }
 
 // CS_VvFullStep (compute:325-334)

@@ -117,3 +117,59 @@ def test_live_phase_edit_lockstep():
         assert np.array_equal(pe[:, 11:14], po[:, 11:14]), f"frame {f}: static fields"
         assert_fields_close(pe, po, 1e-5, f"frame {f}: ")
     eng.destroy(); ora.destroy()
+
+
+def engine_without_pos3():
+    os.environ["SPH_HIP_UNIFORM_MASS"] = "0"    # read once, in sph_create
+    try:
+        return abi.Engine(0)
+    finally:
+        del os.environ["SPH_HIP_UNIFORM_MASS"]
+
+
+@pytest.mark.parametrize("step_frame", [True, False])
+def test_density_12_byte_candidates_equal_16_byte_bitwise(step_frame):
+    """Same mass in every phase: the density kernel reads candidate positions from the 12-byte array the half step
+    left (k_density_pressure_rows<true>).  Same bits as the 16-byte posM path, frame after frame."""
+    a, b = abi.Engine(0), engine_without_pos3()
+    sa, sb = scenes.unity_scene(a, which=4, scale_count=0.05), scenes.unity_scene(b, which=4, scale_count=0.05)
+    sa.sph.use_step_frame = sb.sph.use_step_frame = step_frame
+    sa.sph.subSteps = sb.sph.subSteps = 2          # the second sub-step's positions come from k_half_step
+    sa.start(); sb.start()
+    for f in range(4):
+        sa.frame(); sb.frame()
+        x, y = a.download_particles(), b.download_particles()
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), f"frame {f}"
+    a.destroy(); b.destroy()
+
+
+def test_phases_of_different_mass_take_the_16_byte_path_and_match_the_oracle():
+    """Different particle masses per phase: no uniform-mass shortcut; density still bit-identical to the oracle."""
+    from oracle.ora import Oracle
+    eng, ora = abi.Engine(0), Oracle()
+    se, so = scenes.unity_scene(eng, which=2, scale_count=0.02), scenes.unity_scene(ora, which=2, scale_count=0.02)
+    for sc in (se, so):
+        sc.sph.spawnBoxes[1].particleMass = 0.15
+    se.sph.use_step_frame = True
+    se.start(); so.start()
+    for f in range(3):
+        eng.upload_particles(ora.download_particles())
+        se.frame(); so.frame()
+        x, y = eng.download_particles(), ora.download_particles()
+        assert np.array_equal(x[:, 9].view(np.uint32), y[:, 9].view(np.uint32)), f"frame {f}: density"
+        assert_fields_close(x, y, 1e-5, f"frame {f}: ")
+    eng.destroy(); ora.destroy()
+
+
+def test_uniform_mass_density_is_bitwise_the_oracles():
+    from oracle.ora import Oracle
+    eng, ora = abi.Engine(0), Oracle()
+    se, so = scenes.unity_scene(eng, which=2, scale_count=0.02), scenes.unity_scene(ora, which=2, scale_count=0.02)
+    se.sph.use_step_frame = True
+    se.start(); so.start()
+    for f in range(3):
+        eng.upload_particles(ora.download_particles())
+        se.frame(); so.frame()
+        x, y = eng.download_particles(), ora.download_particles()
+        assert np.array_equal(x[:, 9].view(np.uint32), y[:, 9].view(np.uint32)), f"frame {f}: density"
+    eng.destroy(); ora.destroy()
