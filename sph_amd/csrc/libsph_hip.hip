@@ -1107,6 +1107,9 @@ int sph_slab_upload(sph_ctx* c, const sph_slab_record* records, int n) {
     c->cur = 0; c->velCur = 0; c->gridValid = false; c->maskValid = false;
     c->n = n;
     c->ownedRef.keys = nullptr;       // everything uploaded is owned
+    c->filter.active = 0;             // a rebuild that was waiting for its grid build is void
+    c->bandValid = false;
+    c->armedPack.armed = false;
     c->slabPackedOff = false;
     HIP_TRY(c, hipMemsetAsync(c->phaseMismatch, 0, sizeof(int), c->stream));
     if (n == 0) return SPH_OK;

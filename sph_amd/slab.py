@@ -33,7 +33,10 @@ not on the data path), cut the planes into equal shares and move their faces by 
 Ownership stays that of the last grid build until the next one, so the frame's ordinary face messages carry
 whatever changes hands; no extra exchange.  Results stay bit-identical to a one-GPU run.
 
-Limits of this round: static boundary cube, migration to adjacent slabs only (particles conserved is
+A moving boundary cube (grid origin / cell size / resolution change, SPH.cs:176-185) re-defines the planes:
+the driver then re-partitions from scratch (`_repartition`: download, all-to-all by new owner, upload; slow path).
+
+Limits of this round: migration to adjacent slabs only between re-partitions (particles conserved is
 asserted by `count_global`).
 """
 from __future__ import annotations
@@ -227,6 +230,33 @@ class NeighbourComm:
         self.dist.all_reduce(t)
         return int(t.item())
 
+    def all_to_all_records(self, parts):
+        """parts[r]: records (SLAB_RECORD_DTYPE) for rank r; returns the records every rank had for this one.  Sizes
+        travel in one all-gather, the payload point to point (re-partition after a grid change: rare, not tuned)."""
+        torch, dist = self.torch, self.dist
+        dev = self._dev()
+        counts = torch.tensor([int(x.shape[0]) for x in parts], dtype=torch.int64, device=dev)
+        table = [torch.zeros(self.world, dtype=torch.int64, device=dev) for _ in range(self.world)]
+        dist.all_gather(table, counts)
+        incoming = [int(table[r][self.rank]) for r in range(self.world)]
+        sends, recvs, bufs = [], [], {}
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            if parts[r].shape[0]:
+                t = torch.from_numpy(np.ascontiguousarray(parts[r]).view(np.uint8).reshape(-1, REC).copy()).to(dev)
+                sends.append((t, r))
+            if incoming[r]:
+                bufs[r] = torch.empty((incoming[r], REC), dtype=torch.uint8, device=dev)
+                recvs.append((bufs[r], r))
+        self._xfer(sends, recvs)
+        if not self.stage_cpu and (sends or recvs):
+            torch.cuda.current_stream(self.device).synchronize()
+        got = [np.ascontiguousarray(parts[self.rank])]
+        for r in sorted(bufs):
+            got.append(np.frombuffer(bufs[r].cpu().numpy().tobytes(), dtype=abi.SLAB_RECORD_DTYPE))
+        return np.concatenate(got) if got else np.zeros(0, dtype=abi.SLAB_RECORD_DTYPE)
+
     def allreduce_sum_array(self, a: np.ndarray) -> np.ndarray:
         """Element-wise sum over the ranks of a small int64 array (the per-plane histogram of a re-cut)."""
         t = self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(self._dev())
@@ -330,8 +360,11 @@ class SlabEngine:
     def resize_grid(self, rx, ry, rz, cap):
         if self.grid is not None:
             if self.grid != (rx, ry, rz, cap):
-                raise NotImplementedError("slab mode needs a static grid (boundary cube must not move)")
+                self._new_grid = (rx, ry, rz, cap)     # the boundary cube moved: re-partition at the next set_params
             return
+        self._set_grid(rx, ry, rz, cap)
+
+    def _set_grid(self, rx, ry, rz, cap):
         self.grid = (rx, ry, rz, cap)
         self.cells = rx * ry * rz
         ranges = slab_ranges(rx, self.world)
@@ -379,7 +412,35 @@ class SlabEngine:
         self._params = p
         if self._rows is not None:
             self._distribute()
+        elif (getattr(self, "_new_grid", None) is not None or np.float32(p.minBound[0]) != self._min_x
+              or np.float32(p.cellSize) != self._cell):
+            self._repartition(p)
         self.e.set_params(p)
+
+    def _repartition(self, p):
+        """The boundary cube moved (SPH.cs:176-185 -> 303-346): origin, cell size or resolution of the grid changed,
+        which re-defines every cell plane.  Slow path, rare: every rank takes its own particles off the
+        device, the records go to the ranks that own their planes under the NEW grid, and each rank starts again from
+        its owned particles alone -- the frame's ordinary exchange then supplies the ghosts, as after the initial
+        distribution.  Collective."""
+        recs = self.port.download_owned()
+        grid = getattr(self, "_new_grid", None) or self.grid
+        self._new_grid = None
+        self._min_x, self._cell = np.float32(p.minBound[0]), np.float32(p.cellSize)
+        self._set_grid(*grid)
+        rx, ry, rz, cap = self.grid
+        plane = self._planes(recs["pos"][:, 0])
+        dest = np.searchsorted(np.asarray(self.cuts[1:-1]), plane, side="right")
+        mine = self.comm.all_to_all_records([recs[dest == r] for r in range(self.world)])
+        if mine.shape[0] > self._capacity:
+            raise RuntimeError(f"re-partition: {mine.shape[0]} particles exceed this slab's capacity of {self._capacity}")
+        x0, x1 = self.own
+        self.port.configure(rx, self.keep[0], self.keep[1] - self.keep[0], ry, rz, cap, x0, x1, self._capacity)
+        self.port.upload_owned(mine)
+        self.n = mine.shape[0]
+        self.e.n = self.n
+        self._primed = False          # overlap mode: the next frame gets its ghosts the classic way
+        self.repartitions = getattr(self, "repartitions", 0) + 1
 
     def _distribute(self):
         rx, ry, rz, cap = self.grid
@@ -388,6 +449,7 @@ class SlabEngine:
         self._rows = None
         share = max(self.n_global // self.world, owned.shape[0], 1024)
         capacity = int(share * self.capacity_factor) + 4096
+        self._capacity = capacity
         self.port.configure(rx, self.keep[0], self.keep[1] - self.keep[0], ry, rz, cap, x0, x1, capacity)
         if getattr(self, "_phases", None) and hasattr(self.e, "set_phase_table"):
             self.e.set_phase_table(self._phases)       # before the upload: records are checked against it

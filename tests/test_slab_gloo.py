@@ -30,6 +30,29 @@ def small_tank(engine, n=1500, sub_steps=1):
     return Scene(sph, Time(), [])
 
 
+class _CubeMotion:
+    """Moves the boundary cube every frame (the reference only does this by hand in the editor; SPH.cs:176-185 reacts):
+    'drift' translates it along x (grid origin changes, resolution stays), 'rock' rotates it about z (the AABB and
+    with it the resolution change)."""
+
+    def __init__(self, cube, time, kind):
+        self.cube, self.time, self.kind = cube, time, kind
+
+    def Update(self):
+        from sph_amd.host import quat_from_axis_angle
+        f = self.time.frame
+        if self.kind == "drift":
+            self.cube.position = np.array([0.004 * f, 1.5, 0.0], dtype=np.float32)
+        else:
+            self.cube.rotation = quat_from_axis_angle((0, 0, 1), 0.6 * np.sin(0.7 * f))
+
+
+def moving_tank(engine, kind, n=1500):
+    sc = small_tank(engine, n=n)
+    sc.movers.append(_CubeMotion(sc.sph.boundaryCube, sc.time, kind))
+    return sc
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -38,7 +61,8 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, frames, out_dir, step_frame, ghost=8, rebalance_every=0, sub_steps=1, overlap=False):
+def _worker(rank, world, port, frames, out_dir, step_frame, ghost=8, rebalance_every=0, sub_steps=1, overlap=False,
+            motion=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -54,7 +78,7 @@ def _worker(rank, world, port, frames, out_dir, step_frame, ghost=8, rebalance_e
         oport.set_params_ref(p)
         orig(p)
     se.set_params = set_params
-    sc = small_tank(se, sub_steps=sub_steps)
+    sc = moving_tank(se, motion) if motion else small_tank(se, sub_steps=sub_steps)
     sc.sph.use_step_frame = step_frame
     sc.start()
     counts = []
@@ -65,6 +89,7 @@ def _worker(rank, world, port, frames, out_dir, step_frame, ghost=8, rebalance_e
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), recs)
     np.save(os.path.join(out_dir, f"counts{rank}.npy"), np.array(counts))
     np.save(os.path.join(out_dir, f"cuts{rank}.npy"), np.array(se.cuts + [se.recuts]))
+    np.save(os.path.join(out_dir, f"repart{rank}.npy"), np.array([getattr(se, "repartitions", 0)]))
     dist.destroy_process_group()
 
 
@@ -127,6 +152,27 @@ def test_overlapped_driver_equals_single_domain(tmp_path, oracle_built):
     got = abi.aos_from_records(recs[np.argsort(recs["id"])])
     for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
         assert np.array_equal(got[:, sl], want[:, sl]), "overlapped slab run differs from the single-domain run"
+
+
+@pytest.mark.parametrize("motion", ["drift", "rock"])
+def test_moving_boundary_cube_repartitions_and_equals_single_domain(tmp_path, oracle_built, motion):
+    """The cube moves every frame: the grid (origin, or origin + cell size + resolution) changes under the slabs, the
+    driver re-partitions (download, all-to-all by new owner, upload) and the result is still the single-domain run."""
+    frames = 5
+    from oracle.ora import Oracle
+    ref = Oracle()
+    sc = moving_tank(ref, motion)
+    sc.run(frames)
+    want = ref.download_particles()
+    n = want.shape[0]
+    mp.spawn(_worker, args=(2, _free_port(), frames, str(tmp_path), True, 8, 0, 1, False, motion), nprocs=2, join=True)
+    recs = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(2)])
+    assert int(np.load(tmp_path / "repart0.npy")[0]) >= 2, "the cube moved but the slabs were never re-partitioned"
+    assert np.load(tmp_path / "counts0.npy").tolist() == [n] * frames
+    assert np.array_equal(np.sort(recs["id"]), np.arange(n, dtype=np.uint32))
+    got = abi.aos_from_records(recs[np.argsort(recs["id"])])
+    for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
+        assert np.array_equal(got[:, sl], want[:, sl]), f"moving cube ({motion}): slab run differs from the single-domain run"
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -10,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from sph_amd import abi, slab
-from tests.test_slab_gloo import _free_port, small_tank
+from tests.test_slab_gloo import _free_port, moving_tank, small_tank
 
 pytestmark = pytest.mark.gpu
 
@@ -46,7 +46,10 @@ def _worker(rank, world, port, frames, out_dir, n, ghost, drop_phases, rebalance
         # keep gathering mass and viscosity per particle
         add = se.add_rows
         se.add_rows = lambda first_id, rows, phase=0: add(first_id, rows, 0)
-    sc = (long_tank if tank == "long" else small_tank)(se, n=n, sub_steps=sub_steps)
+    if tank in ("drift", "rock"):
+        sc = moving_tank(se, tank, n=n)
+    else:
+        sc = (long_tank if tank == "long" else small_tank)(se, n=n, sub_steps=sub_steps)
     sc.sph.use_step_frame = True
     sc.start()
     counts = []
@@ -177,6 +180,29 @@ def test_overlapped_exchange_really_splits_the_force_kernel(tmp_path):
     got = abi.aos_from_records(recs[np.argsort(recs["id"])])
     for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
         assert np.array_equal(got[:, sl], want[:, sl]), "split force kernel: slabs differ from one engine"
+
+
+@pytest.mark.parametrize("motion,overlap", [("drift", False), ("rock", False), ("rock", True)])
+def test_moving_boundary_cube_repartitions_bitwise(tmp_path, motion, overlap):
+    """The boundary cube moves every frame (SPH.cs:176-185): the grid changes under the slabs and the driver
+    re-partitions; two ranks still reproduce one engine bit for bit (also when the exchange is overlapped: a
+    re-partition drops the records that were waiting for the next grid build)."""
+    frames, n, world = 6, 3000, 2
+    eng = abi.Engine(0)
+    sc = moving_tank(eng, motion, n=n)
+    sc.sph.use_step_frame = True
+    sc.run(frames)
+    want = eng.download_particles()
+    eng.destroy()
+    n = want.shape[0]
+    mp.spawn(_worker, args=(world, _free_port(), frames, str(tmp_path), n, 8, False, 0, 1, overlap, motion), nprocs=world, join=True)
+    recs = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)])
+    meta = np.load(tmp_path / "meta0.npy")
+    assert meta[:-1].tolist() == [n] * frames, "particles not conserved across slabs"
+    assert np.array_equal(np.sort(recs["id"]), np.arange(n, dtype=np.uint32))
+    got = abi.aos_from_records(recs[np.argsort(recs["id"])])
+    for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
+        assert np.array_equal(got[:, sl], want[:, sl]), f"moving cube ({motion}): 2 slabs differ from one engine"
 
 
 def test_plane_counts_equal_download():
