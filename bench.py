@@ -91,7 +91,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--particles", type=int, default=0, help="override the particle count (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="", help="config2|config3|config4|config5|config5narrow (default: config3)")
+    ap.add_argument("--workload", default="", help="1 GPU: config2|config3|config4|config5|config5narrow (default config3); "
+                                                    "N GPUs: config5 (weak scaling, default) | config4 (strong scaling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

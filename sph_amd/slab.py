@@ -582,11 +582,18 @@ def bench_main(args, rank, local_rank, world):
                                     device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    per_gpu = args.particles or 8388608
+    # default: BASELINE config 5 (weak scaling, 8,388,608 particles per GPU); --workload config4: BASELINE config 4
+    # (strong scaling, 16,777,216 particles in all, --particles overrides the TOTAL)
+    strong = getattr(args, "workload", "") == "config4"
+    if strong:
+        n_all = args.particles or 16777216
+        per_gpu = n_all // world
+    else:
+        per_gpu = args.particles or 8388608
     eng = abi.Engine(local_rank)
-    port = DevicePort(eng, local_rank, msg_capacity=max(per_gpu // 4, 65536))
-    comm = NeighbourComm(rank, world, torch.device("cuda", local_rank), backend=backend,
-                         msg_capacity=max(per_gpu // 4, 65536))
+    msg_cap = max(per_gpu // (2 if strong else 4), 65536)      # narrow slabs: the face band is a large part of a slab
+    port = DevicePort(eng, local_rank, msg_capacity=msg_cap)
+    comm = NeighbourComm(rank, world, torch.device("cuda", local_rank), backend=backend, msg_capacity=msg_cap)
     # config 5 starts balanced and stays so (G equal blocks side by side); SPH_BENCH_REBALANCE=K re-cuts the
     # slabs by particle count every K frames anyway (0 = static cuts)
     # SPH_BENCH_OVERLAP=0: classic order (pack after the frame, exchange before the next one) instead of the
@@ -594,7 +601,7 @@ def bench_main(args, rank, local_rank, world):
     rebalance = int(os.environ.get("SPH_BENCH_REBALANCE", "0"))
     overlap = os.environ.get("SPH_BENCH_OVERLAP", "1") != "0" and not rebalance
     se = SlabEngine(port, comm, rank, world, ghost_planes=8, rebalance_every=rebalance, overlap=overlap)
-    sc = scenes.config5(se, gpus=world, per_gpu=per_gpu)
+    sc = scenes.config4(se, n=n_all) if strong else scenes.config5(se, gpus=world, per_gpu=per_gpu)
     sc.sph.use_step_frame = True
     sc.start()
     for _ in range(args.warmup):
@@ -626,7 +633,7 @@ def bench_main(args, rank, local_rank, world):
     # The same per-GPU load on ONE GPU, no slabs (every rank runs it on its own GPU, concurrently): what
     # "weak scaling" compares with.  bench.py --gpus 1 runs config 3 (1 M particles), a different workload.
     solo = None
-    if os.environ.get("SPH_BENCH_SOLO", "1") != "0":
+    if os.environ.get("SPH_BENCH_SOLO", "1") != "0" and not strong:
         eng.destroy()
         eng = abi.Engine(local_rank)
         s1 = scenes.config5(eng, gpus=1, per_gpu=per_gpu)
@@ -648,8 +655,11 @@ def bench_main(args, rank, local_rank, world):
         print(json.dumps({
             "metric": "particle-updates/sec", "value": n_total * sub * args.steps / dt, "unit": "particle-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"config5: {per_gpu} particles per GPU, {n_total} total, two-phase, x-slabs with "
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": (f"config4: {n_total} particles in all (strong scaling), " if strong else
+                                    f"config5: {per_gpu} particles per GPU, {n_total} total, ") +
+                                   f"two-phase, x-slabs with "
                                    f"8 ghost planes, one neighbour message per face per frame ({backend} send/recv)",
                        "particles": n_total, "sub_steps": sub, "parallelism": f"slab{world}",
                        "halo_violations": viol, "bin_overflow_cells": overflow,
