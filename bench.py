@@ -71,7 +71,7 @@ def cpu_baseline(scene_builder, start_state, frames_done, budget_s=15.0):
     t0 = time.perf_counter()
     sc.frame()                            # untimed warm-up frame (page-faults the bins)
     t1 = time.perf_counter() - t0
-    frames = int(max(1, min(10, budget_s / max(t1, 1e-3))))
+    frames = int(max(1, min(30, budget_s / max(t1, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(frames):
         sc.frame()
