@@ -205,6 +205,28 @@ def test_moving_boundary_cube_repartitions_bitwise(tmp_path, motion, overlap):
         assert np.array_equal(got[:, sl], want[:, sl]), f"moving cube ({motion}): 2 slabs differ from one engine"
 
 
+def test_long_run_overlapped_slabs_bitwise(tmp_path):
+    """120 frames of the long tank on 4 ranks with the overlapped exchange: spawn-density blow-up, fall, impact on the
+    floor, settling against the walls -- conserved, no halo violation, no particle missed by the band, and the same
+    bits as one engine at the end (scripts/soak_slab.py runs the same check for longer)."""
+    frames, world = 120, 4
+    eng = abi.Engine(0)
+    sc = long_tank(eng)
+    sc.sph.use_step_frame = True
+    sc.run(frames)
+    want = eng.download_particles()
+    assert np.isfinite(want).all() and eng.read_counter(abi.CTR_BIN_OVERFLOW) == 0
+    eng.destroy()
+    n = want.shape[0]
+    mp.spawn(_worker, args=(world, _free_port(), frames, str(tmp_path), n, 8, False, 0, 1, True, "long"), nprocs=world, join=True)
+    recs = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)])
+    meta = np.load(tmp_path / "meta0.npy")
+    assert meta[:-1].tolist() == [n] * frames and meta[-1] == 0, meta[-8:]
+    got = abi.aos_from_records(recs[np.argsort(recs["id"])])
+    for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
+        assert np.array_equal(got[:, sl], want[:, sl]), "120 frames: 4 overlapped slabs differ from one engine"
+
+
 def test_plane_counts_equal_download():
     """sph_slab_plane_counts (from the cell table) against the planes of the downloaded records."""
     dist.init_process_group("gloo", rank=0, world_size=1, init_method=f"tcp://127.0.0.1:{_free_port()}")
