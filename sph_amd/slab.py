@@ -42,6 +42,7 @@ asserted by `count_global`).
 from __future__ import annotations
 
 import os
+import sys
 import time
 from typing import Optional
 
@@ -634,20 +635,27 @@ def bench_main(args, rank, local_rank, world):
     # "weak scaling" compares with.  bench.py --gpus 1 runs config 3 (1 M particles), a different workload.
     solo = None
     if os.environ.get("SPH_BENCH_SOLO", "1") != "0" and not strong:
-        eng.destroy()
-        eng = abi.Engine(local_rank)
-        s1 = scenes.config5(eng, gpus=1, per_gpu=per_gpu)
-        s1.sph.use_step_frame = True
-        s1.start()
-        for _ in range(args.warmup):
-            s1.frame()
-        eng.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            s1.frame()
-        eng.synchronize()
-        solo_dt = comm.allreduce_max(time.perf_counter() - t1)
-        solo = per_gpu * s1.sph.subSteps * args.steps / solo_dt
+        # a failure here must not cost the slab result, nor leave the other ranks waiting in the reduction
+        solo_dt = float("inf")
+        try:
+            eng.destroy()
+            eng = abi.Engine(local_rank)
+            s1 = scenes.config5(eng, gpus=1, per_gpu=per_gpu)
+            s1.sph.use_step_frame = True
+            s1.start()
+            for _ in range(args.warmup):
+                s1.frame()
+            eng.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                s1.frame()
+            eng.synchronize()
+            solo_dt = time.perf_counter() - t1
+        except Exception as exc:                     # noqa: BLE001 - reported, not fatal
+            print(f"[bench] rank {rank}: one-GPU reference run failed: {exc}", file=sys.stderr)
+        solo_dt = comm.allreduce_max(solo_dt)
+        if solo_dt != float("inf"):
+            solo = per_gpu * sc.sph.subSteps * args.steps / solo_dt
     if rank == 0:
         sub = sc.sph.subSteps
         n_local = se.n
