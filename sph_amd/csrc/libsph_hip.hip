@@ -107,6 +107,7 @@ struct sph_ctx {
     float* pos3 = nullptr;            // x, y, z per slot (12 bytes): candidate positions of the density kernel's fast path
     bool pos3Valid = false;           // written by the half step that produced the current positions
     bool slabMismatchClean = false;   // slab mode: phaseMismatch was read as 0 at the last grid build (covers this frame's records)
+    bool skipGhostForce = true;       // SPH_HIP_GHOST_FORCE=1 switches the skip off (A/B)
     bool uniformMassOk = true;        // SPH_HIP_UNIFORM_MASS=0 switches the 12-byte candidate path off (A/B)
     int cachedMisses = -1;            // SPH_CTR_BAND_MISSES as read along with the survivor count of a slab build
     bool slabPackedOff = false;       // the phase table changed after the records were uploaded
@@ -241,7 +242,7 @@ void deriveParams(sph_ctx* c) {
     d.spikyGradFactor = -45.0f / (PI * powf(h, 6.0f));
     d.viscLapFactor = 45.0f / (PI * powf(h, 6.0f));
     d.lapColFactor = 1890.0f / (64.0f * PI * powf(h, 9.0f));
-    d.wgBand = nullptr; d.wgPhase = -1;
+    d.wgBand = nullptr; d.wgPhase = -1; d.ghostKeys = nullptr;
 }
 
 int checkReady(sph_ctx* c, bool needGrid) {
@@ -421,6 +422,8 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
     c->dp.n = n;
     c->dp.wgBand = wgPhase >= 0 ? c->wgBand : (const uint8_t*)nullptr;
     c->dp.wgPhase = wgPhase;
+    c->dp.ghostKeys = (id == SPH_K_FORCE_XSPH && c->slab && fused && lastSub && c->skipGhostForce) ? (const uint32_t*)c->sortedKeys
+                                                                                                  : (const uint32_t*)nullptr;
     if (n == 0 && id != SPH_K_CLEAR_GRID && id != SPH_K_BUILD_GRID) {   // an empty slab has nothing to launch
         if (id < SPH_K_CLEAR || id > SPH_K_VELOCITY_DAMPING) return fail(c, SPH_E_INVALID, "bad kernel id %d", id);
         return SPH_OK;
@@ -555,6 +558,7 @@ int sph_create(sph_ctx** out, int device_id) {
     if (const char* xr = getenv("SPH_HIP_XCD_RUN")) c->xcdRunOverride = atoi(xr);
     if (const char* dbg = getenv("SPH_HIP_DEBUG")) c->debug = atoi(dbg) != 0;
     if (const char* um = getenv("SPH_HIP_UNIFORM_MASS")) c->uniformMassOk = atoi(um) != 0;
+    if (const char* gf = getenv("SPH_HIP_GHOST_FORCE")) c->skipGhostForce = atoi(gf) == 0;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return SPH_E_HIP;
@@ -858,7 +862,7 @@ int sph_step_frame(sph_ctx* c, int sub_steps, float time_step) {
         if ((rc = dispatchKernel(c, SPH_K_DENSITY_PRESSURE))) return rc;
         if (last && tl >= 1) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
         if (last && split) {
-            if ((rc = dispatchKernel(c, SPH_K_FORCE_XSPH, true, false, 1))) return rc;      // band workgroups
+            if ((rc = dispatchKernel(c, SPH_K_FORCE_XSPH, true, last, 1))) return rc;       // band workgroups
             StateSet st = c->set[c->cur];
             st.velV = c->set[1 - c->velCur].velV;                                           // what the force launch wrote
             hipLaunchKernelGGL(k_slab_pack_final, dim3((c->n + kBlock * kKeepItems - 1) / (kBlock * kKeepItems)), dim3(kBlock), 0,
@@ -876,7 +880,7 @@ int sph_step_frame(sph_ctx* c, int sub_steps, float time_step) {
             c->bandValid = split;
             c->bandSendLo = ap.leftBelow; c->bandSendHi = ap.rightFrom;
         }
-        if ((rc = dispatchKernel(c, SPH_K_FORCE_XSPH, true, false, last && split ? 0 : -1))) return rc;
+        if ((rc = dispatchKernel(c, SPH_K_FORCE_XSPH, true, last, last && split ? 0 : -1))) return rc;
         if (last && tl >= 1) HIP_TRY(c, hipEventRecord(ev[4], c->stream));
         if ((rc = dispatchKernel(c, SPH_K_VV_FULL_STEP, true, last))) return rc;
         if (last && tl >= 2) {

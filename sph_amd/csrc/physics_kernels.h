@@ -405,6 +405,10 @@ __device__ __forceinline__ ForceSelf force_load_self(const DevParams& P, int s, 
     const float2 dp = rhoP[me.sl];
     me.densitySelf = dp.x;
     me.live = valid && !(me.densitySelf < 1e-6f);                          // compute:207-211
+    if (P.ghostKeys && valid) {                                            // slab mode: see DevParams::ghostKeys
+        const int plane = (int)(P.ghostKeys[s] % (uint32_t)P.rx);
+        me.live = me.live && plane >= P.ownLo && plane < P.ownHi;
+    }
     me.selfTerm = dp.y / (me.densitySelf * me.densitySelf);
     return me;
 }

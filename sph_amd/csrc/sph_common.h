@@ -42,6 +42,9 @@ struct DevParams {
     // wgBand[wg] == wgPhase (null: every workgroup runs)
     const uint8_t* wgBand;
     int   wgPhase;
+    // slab mode, last sub-step of a fused frame: keys of the last grid build; CS_ForceXSPH skips the ghost slots
+    // (their state is dropped by the next exchange, nobody reads what the force kernel would write)
+    const uint32_t* ghostKeys;
 };
 
 // ---- memory order of the cells ("row tiles") --------------------------------------------------------
