@@ -243,13 +243,29 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
         r = nxt;
     }
     if (recording) {
-        const int nWords = min(wi, kMaskStage);
-        uint4* const row = (uint4*)mrowG;
+        static_assert(kMaskStage == 16, "a mask row is four 16-byte quads");
+        const int tile = s - (int)threadIdx.x;
+        if (tile + kBlock <= P.n) {
+            // Full workgroup: every wave writes its 64 rows (4 KB, contiguous) TRANSPOSED -- an instruction covers
+            // 1 KB = 8 lines instead of one quad of each of 64 rows = 32 lines (the kernel is bound by the lines
+            // its memory instructions touch).  Words past a particle's count are whatever LDS held: never read.
+            __syncthreads();
+            const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
+            uint4* const wrow = (uint4*)(hitMask + (size_t)(tile + wbase) * kMaskStage);
 #pragma unroll
-        for (int q = 0; q < kMaskStage / 4; q++)
-            if (q * 4 < nWords)
-                row[q] = make_uint4(maskStage[q * 4][threadIdx.x], maskStage[q * 4 + 1][threadIdx.x],
-                                    maskStage[q * 4 + 2][threadIdx.x], maskStage[q * 4 + 3][threadIdx.x]);
+            for (int k = 0; k < 4; k++) {
+                const int e = lane + 64 * k, col = wbase + (e >> 2), q4 = (e & 3) * 4;
+                wrow[e] = make_uint4(maskStage[q4][col], maskStage[q4 + 1][col], maskStage[q4 + 2][col], maskStage[q4 + 3][col]);
+            }
+        } else {
+            const int nWords = min(wi, kMaskStage);
+            uint4* const row = (uint4*)mrowG;
+#pragma unroll
+            for (int q = 0; q < kMaskStage / 4; q++)
+                if (q * 4 < nWords)
+                    row[q] = make_uint4(maskStage[q * 4][threadIdx.x], maskStage[q * 4 + 1][threadIdx.x],
+                                        maskStage[q * 4 + 2][threadIdx.x], maskStage[q * 4 + 3][threadIdx.x]);
+        }
     }
     const float r0 = rho0[s];
     density = fmaxf(density, r0);                                          // compute:186
@@ -510,13 +526,39 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
         const uint4* __restrict__ mlo = (const uint4*)(hitMask + (size_t)me.sl * kMaskStage);
         const uint4* __restrict__ mhi = (const uint4*)(hitMask + (size_t)maskStride * kMaskStage +
                                                        (size_t)me.sl * (kMaskWords - kMaskStage)) - kMaskStage / 4;
+        const int tile = wg * kBlock;
+        if (tile + kBlock <= P.n) {
+            // Full workgroup: the wave reads its 64 rows' first 16 words (4 KB, contiguous) TRANSPOSED: an
+            // instruction covers 1 KB = 8 lines instead of one quad of each of 64 rows = 32 lines.  Only this wave's
+            // columns of wordOf are touched, so a wave-level barrier orders the LDS writes before the reads below.
+            const int lane = tid & 63, wbase = tid & ~63;
+            const uint4* __restrict__ wrow = (const uint4*)(hitMask + (size_t)(tile + wbase) * kMaskStage);
 #pragma unroll
-        for (int q = 0; q < kMaskWords / 4; q++)
-            if (q * 4 < nWords) {
-                const uint4 v = q < kMaskStage / 4 ? mlo[q] : mhi[q];
-                wordOf[q * 4][tid] = (int)v.x; wordOf[q * 4 + 1][tid] = (int)v.y;
-                wordOf[q * 4 + 2][tid] = (int)v.z; wordOf[q * 4 + 3][tid] = (int)v.w;
+            for (int k = 0; k < 4; k++) {
+                const int e = lane + 64 * k, col = wbase + (e >> 2), q4 = (e & 3) * 4;
+                const uint4 v = wrow[e];
+                wordOf[q4][col] = (int)v.x; wordOf[q4 + 1][col] = (int)v.y;
+                wordOf[q4 + 2][col] = (int)v.z; wordOf[q4 + 3][col] = (int)v.w;
             }
+#pragma unroll
+            for (int q = kMaskStage / 4; q < kMaskWords / 4; q++)
+                if (q * 4 < nWords) {
+                    const uint4 v = mhi[q];
+                    wordOf[q * 4][tid] = (int)v.x; wordOf[q * 4 + 1][tid] = (int)v.y;
+                    wordOf[q * 4 + 2][tid] = (int)v.z; wordOf[q * 4 + 3][tid] = (int)v.w;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+#pragma unroll
+            for (int q = 0; q < kMaskWords / 4; q++)
+                if (q * 4 < nWords) {
+                    const uint4 v = q < kMaskStage / 4 ? mlo[q] : mhi[q];
+                    wordOf[q * 4][tid] = (int)v.x; wordOf[q * 4 + 1][tid] = (int)v.y;
+                    wordOf[q * 4 + 2][tid] = (int)v.z; wordOf[q * 4 + 3][tid] = (int)v.w;
+                }
+        }
         // 2) keep the non-empty words, each with its row and its place in the row (in place: the
         //    write position never overtakes the read position)
         int cnt = 0, idx = 0;
