@@ -220,12 +220,13 @@ void deriveParams(sph_ctx* c) {
     d.ry = q.gridResolutionY; d.rz = q.gridResolutionZ;
     d.rxg = q.gridResolutionX;
     d.ryT = tiles_along(d.ry, kTileYLog);
-    {   // XCD run length (see xcd_tile): 16 runs per XCD, between 16 and 512 workgroups.  Measured on
-        // config 3 (1 M particles: 32 best) and config 5 (8.4 M: 128-512 best, 16 is 25 % slower).
+    {   // XCD run length (see xcd_tile): 32 runs per XCD, between 16 and 128 workgroups.  Measured on the final
+        // kernels (scripts/gpu_xcd.sh): config 3 (1 M particles) is flat from 16 to 48 and loses 2 % at 96; config 5
+        // (8.4 M) is best at 64-128 (2.77 ms), 256 costs 1.5 %, 1024 6 %, 16 2 %.
         const int nwg = (c->n + kBlock - 1) / kBlock;
-        int run = nwg / 128;
+        int run = nwg / 256;
         if (run < 16) run = 16;
-        if (run > 512) run = 512;
+        if (run > 128) run = 128;
         d.xcdRun = c->xcdRunOverride > 0 ? c->xcdRunOverride : run;
     }
     d.xoff = c->slab ? c->xOffset : 0;
