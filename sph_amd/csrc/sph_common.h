@@ -56,7 +56,13 @@ struct DevParams {
 //   key = x + rx * row_index(y, z),  row_index = tile(y>>a, z>>b) * (kTileY*kTileZ) + (z&mz)*kTileY + (y&my)
 // so that eight of the nine rows a particle reads are (mostly) within a few hundred KB of its own.
 // Only the layout changes: bins, visiting order and every exported quantity are the reference's.
-constexpr int kTileYLog = 3, kTileZLog = 3;
+#ifndef SPH_TILE_Y_LOG
+#define SPH_TILE_Y_LOG 3
+#endif
+#ifndef SPH_TILE_Z_LOG
+#define SPH_TILE_Z_LOG 3
+#endif
+constexpr int kTileYLog = SPH_TILE_Y_LOG, kTileZLog = SPH_TILE_Z_LOG;
 constexpr int kTileY = 1 << kTileYLog, kTileZ = 1 << kTileZLog;
 
 __host__ __device__ __forceinline__ int row_index(int ryT, int y, int z) {
