@@ -601,7 +601,10 @@ def bench_main(args, rank, local_rank, world):
     # in-frame pack whose exchange runs under the second half of the frame
     rebalance = int(os.environ.get("SPH_BENCH_REBALANCE", "0"))
     overlap = os.environ.get("SPH_BENCH_OVERLAP", "1") != "0" and not rebalance
-    se = SlabEngine(port, comm, rank, world, ghost_planes=8, rebalance_every=rebalance, overlap=overlap)
+    # 12 ghost planes: at the spawn density of configs 4/5 (7 x rest density) the first frames throw particles up to
+    # 5 cell planes per frame (scripts/max_shift.py), and the halo condition is ghost >= 2 (1 + shift); 2-3 planes later
+    ghost = int(os.environ.get("SPH_BENCH_GHOST", "12"))
+    se = SlabEngine(port, comm, rank, world, ghost_planes=ghost, rebalance_every=rebalance, overlap=overlap)
     sc = scenes.config4(se, n=n_all) if strong else scenes.config5(se, gpus=world, per_gpu=per_gpu)
     sc.sph.use_step_frame = True
     sc.start()
@@ -668,7 +671,7 @@ def bench_main(args, rank, local_rank, world):
             "config": {"workload": (f"config4: {n_total} particles in all (strong scaling), " if strong else
                                     f"config5: {per_gpu} particles per GPU, {n_total} total, ") +
                                    f"two-phase, x-slabs with "
-                                   f"8 ghost planes, one neighbour message per face per frame ({backend} send/recv)",
+                                   f"{ghost} ghost planes, one neighbour message per face per frame ({backend} send/recv)",
                        "particles": n_total, "sub_steps": sub, "parallelism": f"slab{world}",
                        "halo_violations": viol, "bin_overflow_cells": overflow,
                        "rebalance_every": se.rebalance_every, "recuts": se.recuts,
