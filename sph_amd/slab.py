@@ -449,7 +449,11 @@ class SlabEngine:
         owned = np.concatenate(self._rows) if self._rows else np.zeros(0, dtype=abi.SLAB_RECORD_DTYPE)
         self._rows = None
         share = max(self.n_global // self.world, owned.shape[0], 1024)
-        capacity = int(share * self.capacity_factor) + 4096
+        # room for the ghosts of both faces and, between a rebuild and its grid build, for the records just received
+        # on top of last frame's ghosts: 4 ghost widths on top of the owned planes (narrow slabs: config 4 on 8 GPUs)
+        width = max(x1 - x0, 1)
+        factor = max(self.capacity_factor, 1.25 * (1.0 + 4.0 * self.ghost / width)) if self.world > 1 else self.capacity_factor
+        capacity = int(share * factor) + 4096
         self._capacity = capacity
         self.port.configure(rx, self.keep[0], self.keep[1] - self.keep[0], ry, rz, cap, x0, x1, capacity)
         if getattr(self, "_phases", None) and hasattr(self.e, "set_phase_table"):
