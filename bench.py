@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- particle-updates/s of the SPH frame step on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W
 
 A "step" is one frame of SPH.Update (SPH.cs:201-222: grid build + subSteps x {half-step, clear,
 density, force, full-step, boundary} + damping) over the resident particle set.  At N=1 the
@@ -9,50 +9,109 @@ workload is BASELINE config 3 (configs[2]): 1,048,576 particles, two-phase, orbi
 obstacle, rocking boundary cube -- the 1M-particle configuration the metric is quoted on.
 Particles are synthetic (seeded uniform spawn, ORACLE rule O9) and already resident in HBM
 when the timed region starts.  Prints ONE JSON line on rank 0.
+
+N > 1: one process per GPU.  Under a launcher (torchrun: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+environment) this process is one rank.  Started plainly (`python bench.py --gpus N`, WORLD_SIZE unset) it
+is the PARENT: it starts N rank processes of itself with that environment -- before it has made any GPU,
+HIP or torch call, and without ever replacing a process image -- relays rank 0's JSON line and exits
+non-zero if any rank failed (launch_plan / run_ranks below; tests/test_bench_launcher.py).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
-HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
-FORCE_BYTES_PER_PARTICLE = 64   # SURVEY 8(d): R pos12 vel12 rho4 p4 visc4 mass4; W acc12 vel12
-DENSITY_BYTES_PER_PARTICLE = 28
 
 
-def measured_traffic(kernel, workload, n):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r1_traffic.json,
-    collected with scripts/gpu_pmc.sh in separate --pmc runs); None if not measured for this workload."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-        if t["workload"] != workload or t["particles"] != n:
-            return None
-        k = t["kernels"][kernel]
-        return (2.0 * k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"]) * 1024.0
-    except Exception:
-        return None
+# ------------------------------------------------------------------------------------------------
+# self-launch of the N ranks (VERDICT r1 #2)
+# ------------------------------------------------------------------------------------------------
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
 
 
-def valu_issue(kernel, workload, n, launch_ms):
-    """Secondary roofline of a neighbour kernel: VALU wave-instructions per launch (SQ_INSTS_VALU from the
-    committed PMC pass of this workload) / live launch time, against the issue rate measured on this
-    chip (scripts/experiments/valu_rate.hip).  These kernels are bound by candidate tests, not by HBM."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-        if t["workload"] != workload or t["particles"] != n:
-            return None
-        insts = t["kernels"][kernel]["SQ_INSTS_VALU"]
-        peak = t["valu_issue_peak"]["wave_insts_per_s_per_simd"] * t["valu_issue_peak"]["simds"] / 1e9
-        ach = insts / (launch_ms * 1e-3) / 1e9
-        return {"wave_insts_per_launch": insts, "achieved": ach, "peak": peak, "unit": "G wave-inst/s", "frac": ach / peak}
-    except Exception:
-        return None
+def launch_plan(argv, n_ranks, port=None, python=None, script=None, base_env=None):
+    """[(cmd, env)] for the n_ranks processes of one node: the same command line, torchrun's environment
+    contract (RANK, LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR = 127.0.0.1, MASTER_PORT)."""
+    port = int(port or free_port())
+    python = python or sys.executable
+    script = script or os.path.abspath(__file__)
+    base = dict(os.environ if base_env is None else base_env)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
+    plan = []
+    for r in range(n_ranks):
+        env = dict(base)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPH_BENCH_SELF_LAUNCHED="1")
+        plan.append(([python, "-u", script] + list(argv), env))
+    return plan
+
+
+def run_ranks(plan, poll_s=0.2):
+    """Start every rank as a CHILD process, wait for all.  Rank 0's stdout is captured, the other ranks' goes to
+    stderr.  If a rank fails, the others are ended (their exact PIDs) and its code is returned.  Returns
+    (return_code, rank0_stdout)."""
+    procs = []
+    for r, (cmd, env) in enumerate(plan):
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    live = set(range(len(procs)))
+    while live:
+        for r in list(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"[bench] rank {r} exited with {code}; ending the other ranks", file=sys.stderr)
+                for q in live:
+                    procs[q].terminate()
+        if live:
+            time.sleep(poll_s)
+    for p in procs:                 # a rank that ignored SIGTERM
+        try:
+            p.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    reader.join(timeout=10)
+    return rc, (out0[0] if out0 else "")
+
+
+def pick_json_line(text):
+    """The last line of `text` that is a JSON object with a "metric" key (rank 0's result line)."""
+    for line in reversed(text.splitlines()):
+        line = line.strip()
+        if line.startswith("{"):
+            try:
+                d = json.loads(line)
+            except ValueError:
+                continue
+            if "metric" in d:
+                return line
+    return None
+
+
+def self_launch(argv, n_ranks):
+    rc, out = run_ranks(launch_plan(argv, n_ranks))
+    line = pick_json_line(out)
+    if rc != 0 or line is None:
+        sys.stderr.write(out)
+        raise SystemExit(rc or 1)
+    print(line)
+    return 0
 
 
 def cpu_baseline(scene_builder, start_state, frames_done, budget_s=15.0):
@@ -79,12 +138,13 @@ def cpu_baseline(scene_builder, start_state, frames_done, budget_s=15.0):
     ups = n * sc.sph.subSteps * frames / dt
     out = {"value": ups, "unit": "particle-updates/s", "cores": ora.threads(), "kind": "port",
            "sample": f"{frames} frames of the same {n}-particle workload from the post-warm-up state, "
-                     f"OpenMP oracle (g++ -O2 -fopenmp, no -march), {dt:.1f} s"}
+                     f"OpenMP oracle (g++ -O2 -fopenmp, no -march: built in the CPU container, runs on the GPU box's "
+                     f"different host CPU), {dt:.1f} s"}
     ora.destroy()
     return out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -93,15 +153,25 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="", help="1 GPU: config2|config3|config4|config5|config5narrow (default config3); "
                                                     "N GPUs: config5 (weak scaling, default) | config4 (strong scaling)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process only starts the ranks (nothing GPU-related is imported yet)
+        return self_launch(argv, args.gpus)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world != 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     from sph_amd import abi, scenes
+    from sph_amd.benchutil import (DENSITY_BYTES_PER_PARTICLE, FORCE_BYTES_PER_PARTICLE, HBM_PEAK_GBPS, MEASURED_LIMITER,
+                                   counter_run, measured_traffic, ta_busy_frac, valu_issue)
 
     if args.gpus > 1:
         from sph_amd import slab
@@ -116,6 +186,9 @@ def main():
         "config5narrow": lambda e: scenes.config5(e, gpus=1, per_gpu=args.particles or 8388608, block=(20.0, 256.0)),
     }
     builder = builders[wl]
+    # kernel times come from hipEvents the library records on ITS stream; a short timed region (the driver's 20
+    # frames) records them on every frame, a long one on every 4th (an event costs stream time)
+    os.environ.setdefault("SPH_HIP_TIMING_STRIDE", "1" if args.steps <= 32 else "4")
     eng = abi.Engine(local_rank)
     sc = builder(eng)
     sc.sph.use_step_frame = True
@@ -136,14 +209,16 @@ def main():
         sc.frame()
     eng.synchronize()
     dt = time.perf_counter() - t0
-    tm = eng.get_timings()                # hipEvents on the engine's stream, averaged over the K frames
+    tm = eng.get_timings()                # hipEvents on the engine's stream, averaged over the timed frames
     overflow = eng.read_counter(abi.CTR_BIN_OVERFLOW)
+    non_finite = eng.read_counter(abi.CTR_NAN)
 
     sub = sc.sph.subSteps
     value = n * sub * args.steps / dt
-    force_s = tm["force_ms"] * 1e-3 / 1.0
+    force_s = tm["force_ms"] * 1e-3
     achieved = FORCE_BYTES_PER_PARTICLE * n / force_s / 1e9
     dens_gbps = DENSITY_BYTES_PER_PARTICLE * n / (tm["density_ms"] * 1e-3) / 1e9
+    run = counter_run(wl, n, args.warmup)
     result = {
         "metric": "particle-updates/sec",
         "value": value,
@@ -160,24 +235,30 @@ def main():
         "config": {"workload": f"{wl}: {n} particles, two-phase, subSteps {sub}, "
                                f"grid {sc.sph.gridResolutionX}x{sc.sph.gridResolutionY}x{sc.sph.gridResolutionZ}",
                    "particles": n, "sub_steps": sub, "parallelism": "1 GPU",
-                   "bin_overflow_cells": overflow},
-        "roofline": {"bound": "hbm", "kernel": "k_force_xsph_hits (CS_ForceXSPH)", "achieved": achieved,
+                   "bin_overflow_cells": overflow, "non_finite_particles": non_finite,
+                   "frames_with_kernel_events": tm["frames"]},
+        "roofline": {"bound": "hbm", "measured_limiter": MEASURED_LIMITER,
+                     "kernel": "k_force_xsph_hits (CS_ForceXSPH)", "achieved": achieved,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": measured_traffic("k_force_xsph_hits", wl, n),
+                     "traffic": measured_traffic(run, "k_force_xsph_hits"),
+                     "traffic_from": None if run is None else f"warmup {run['warmup']}, steps {run['steps']} ({run.get('source', 'profiles/')})",
                      "alg_bytes_per_particle": FORCE_BYTES_PER_PARTICLE, "avg_launch_ms": tm["force_ms"],
-                     "valu_issue": valu_issue("k_force_xsph_hits", wl, n, tm["force_ms"]),
+                     "valu_issue": valu_issue(run, "k_force_xsph_hits", tm["force_ms"]),
+                     "ta_busy_frac": ta_busy_frac(run, "k_force_xsph_hits", tm["force_ms"]),
                      "density_kernel": {"achieved": dens_gbps, "frac": dens_gbps / HBM_PEAK_GBPS,
                                         "alg_bytes_per_particle": DENSITY_BYTES_PER_PARTICLE,
                                         "avg_launch_ms": tm["density_ms"],
-                                        "traffic": measured_traffic("k_density_pressure_rows", wl, n),
-                                        "valu_issue": valu_issue("k_density_pressure_rows", wl, n, tm["density_ms"])}},
+                                        "traffic": measured_traffic(run, "k_density_pressure_rows"),
+                                        "valu_issue": valu_issue(run, "k_density_pressure_rows", tm["density_ms"]),
+                                        "ta_busy_frac": ta_busy_frac(run, "k_density_pressure_rows", tm["density_ms"])}},
         "stage_ms": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
     }
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(builder, start_state, args.warmup)
     eng.destroy()
     print(json.dumps(result))
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -85,7 +85,7 @@ namespace SphHip
     }
 
     /// enum sph_counter.
-    public enum SphCounter { Collisions = 0, BinOverflow = 1, OutOfGrid = 2, MaxPlaneShift = 3 }
+    public enum SphCounter { Collisions = 0, BinOverflow = 1, OutOfGrid = 2, MaxPlaneShift = 3, BandMisses = 4, NonFinite = 5 }
 
     public static class Native
     {

@@ -110,7 +110,12 @@ enum sph_counter {
                                  plane of the send range without being in a band workgroup, i.e. that were NOT
                                  sent (can only happen when the halo condition is violated too); counted by
                                  the grid build that follows                                                  */
-    SPH_CTR_COUNT        = 5
+    SPH_CTR_NAN          = 5, /* failure detection: particles whose position or velocity was not finite when a
+                                 boundary pass (CS_BoundObs, or the fused tail of sph_step_frame) wrote them, since
+                                 the last grid build; a particle that stays non-finite counts once per sub-step.
+                                 Slab mode: owned particles only.  Never an error: the frame goes on, like the
+                                 reference's would                                                              */
+    SPH_CTR_COUNT        = 6
 };
 
 typedef struct sph_ctx sph_ctx;

@@ -1,7 +1,7 @@
 """sph_ref.py -- independent numpy restatement of the SPH frame step.  TEST INFRASTRUCTURE ONLY.
 
 A second, structurally different statement of Assets/SPHCompute.compute ("compute:line") used
-only to cross-check oracle/sph_oracle.cpp (tests/test_oracle_vs_numpy.py) and the golden
+only to cross-check oracle/sph_oracle.cpp (tests/test_golden_oracle.py, tests/golden/make_golden.py) and the golden
 fixtures.  It has no grid at all: candidate pairs come from a brute-force N x N test on cell
 coordinates (|bin cell of j - unclamped search cell of i| <= 1 per axis, the bin-capacity rule
 applied by id rank), so a bug in the oracle's bin bookkeeping cannot hide here.  Neighbour

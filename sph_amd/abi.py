@@ -20,7 +20,7 @@ K_CLEAR, K_CLEAR_GRID, K_BUILD_GRID, K_DENSITY_PRESSURE, K_FORCE_XSPH, K_VV_HALF
 KERNEL_NAMES = ["CS_Clear", "CS_ClearGrid", "CS_BuildGrid", "CS_DensityPressure", "CS_ForceXSPH",
                 "CS_VvHalfStep", "CS_VvFullStep", "CS_BoundObs", "CS_VelocityDamping"]
 
-CTR_COLLISIONS, CTR_BIN_OVERFLOW, CTR_OUT_OF_GRID, CTR_MAX_PLANE_SHIFT, CTR_BAND_MISSES = range(5)
+CTR_COLLISIONS, CTR_BIN_OVERFLOW, CTR_OUT_OF_GRID, CTR_MAX_PLANE_SHIFT, CTR_BAND_MISSES, CTR_NAN = range(6)
 SLAB_RECORD_BYTES = 64
 
 # every symbol include/sph_hip.h declares (checked by tests/test_abi.py)

@@ -216,19 +216,46 @@ __global__ __launch_bounds__(kBlock) void k_place(int n, const uint32_t* __restr
 // statements as k_half_step, so positions and velocities are bit-identical to reorder-then-half-step;
 // acceleration is consumed here and density / pressure are dead (the neighbour kernels overwrite all
 // three before anything reads them), so they are not carried over.
+constexpr int kRankSerialMax = 64;   // cells up to this many particles are ranked by a serial scan per thread
 template <bool HALF>
 __global__ __launch_bounds__(kBlock) void k_rank_move(const uint32_t* __restrict__ sortedKeys,
                                                       const uint32_t* __restrict__ perm,
                                                       const uint32_t* __restrict__ sid, int n, int cap, float dt,
                                                       const int* __restrict__ cellCum, StateSet src, StateSet dst,
                                                       int* __restrict__ counters, float* __restrict__ pos3) {
-    int k = blockIdx.x * kBlock + threadIdx.x;
-    if (k >= n) return;
-    const uint32_t c = sortedKeys[k];
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = k < n;                            // lanes past the end stay active for the wave-wide ranking below
+    const int kk = valid ? k : n - 1;
+    const uint32_t c = sortedKeys[kk];
     const int a = cellCum[c], e = cellCum[c + 1];
-    const uint32_t me = sid[k];
+    const uint32_t me = sid[kk];
     int r = 0;
-    for (int j = a; j < e; j++) r += (sid[j] < me) ? 1 : 0;
+    // Usual cells (a handful of particles): every thread scans its own cell.  CROWDED cells -- every escaped particle
+    // is clamped into a boundary cell (compute:126) and a NaN position hashes to cell 0, so a diverged run can put
+    // 10^5..10^6 particles into one bin -- are ranked by the wave together: the cell's ids are read 64 at a time
+    // with ONE coalesced load per chunk and every lane of that cell counts the chunk's ids below its own through
+    // lane broadcasts (O(pop^2 / 64) instructions and O(pop^2 / 4096) loads per cell instead of O(pop^2) dependent
+    // loads per thread, which at 10^6 particles in a bin was effectively a hang).
+    const bool crowded = valid && e - a > kRankSerialMax;
+    if (!crowded)
+        for (int j = a; j < e; j++) r += (sid[j] < me) ? 1 : 0;
+    const int lane = threadIdx.x & 63;
+    unsigned long long pending = __ballot(crowded);
+    while (pending) {                                    // wave-uniform: one trip per distinct crowded cell of this wave
+        const int src = __builtin_ctzll(pending);
+        const int la = __shfl(a, src), le = __shfl(e, src);
+        const bool mine = crowded && a == la;
+        int rb = 0;
+        for (int base = la; base < le; base += 64) {
+            const int idx = base + lane;
+            const uint32_t v = idx < le ? sid[idx] : 0xFFFFFFFFu;     // ids are < 2^28: the filler is below nobody
+#pragma unroll
+            for (int l = 0; l < 64; l++) rb += (uint32_t)__builtin_amdgcn_readlane((int)v, l) < me ? 1 : 0;
+        }
+        if (mine) r = rb;
+        pending &= ~__ballot(mine);
+    }
+    if (!valid) return;
     if (k == a && e - a > cap) atomicAdd(&counters[SPH_CTR_BIN_OVERFLOW], 1);
     const uint32_t s = perm[k];
     const int d = a + r;

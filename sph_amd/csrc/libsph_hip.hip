@@ -23,7 +23,7 @@ namespace {
 
 constexpr int kNumEvents = 8;    // stage boundaries of one frame
 constexpr int kTimingRing = 32;  // frames whose events may be outstanding
-constexpr int kTimingStride = 4;  // SPH_HIP_TIMING=1: frames between timed frames (an event costs ~5 us of stream time)
+constexpr int kTimingStride = 4;  // SPH_HIP_TIMING=1: frames between timed frames (an event costs stream time); SPH_HIP_TIMING_STRIDE overrides
 
 struct DevBuf {
     void* p = nullptr;
@@ -128,6 +128,8 @@ struct sph_ctx {
     int ringNext = 0;
     double stageSum[kNumEvents] = {};   // ms; [7] = whole frame
     int timingLevel = 1;                // 0 none, 1 frame + density + force on sampled frames (default), 2 every stage
+    int timingStride = kTimingStride;   // level 1: every this-many-th frame is timed
+    unsigned eventFlags = hipEventDisableSystemFence;   // SPH_HIP_EVENT_FENCE=1: default events (A/B)
     int framesSinceHarvest = 0;         // level 1 records events on every kTimingStride-th frame only
     int framesTimed = 0;
 };
@@ -433,6 +435,7 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
     StateSet s = curSet(c);
     switch (id) {
         case SPH_K_CLEAR:
+            c->packedValid = false;   // density / pressure change under the packed neighbour records
             hipLaunchKernelGGL(k_clear, dim3(nb), dim3(kBlock), 0, c->stream, n, s.acc, s.rhoP, s.rho0);
             break;
         case SPH_K_CLEAR_GRID:
@@ -443,7 +446,11 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
             // packed neighbour records: only while every particle's mass / viscosity IS its phase's row
             // (one GPU: the table has been applied; slab mode: the records came with phase ids and the
             // table has not changed since -- records that disagree with it raise phaseMismatch)
-            const bool tableOk = !c->phaseTable.empty() && c->phaseTable.size() <= 4;
+            // ... and the phase id rides in the SIGN bits of density and pressure: density >= rest density > 0 and
+            // Tait pressure B ((rho/rho0)^gamma - 1) >= 0 need restDensity > 0 in every phase and gamma > 0 (both are
+            // Inspector-editable in the reference); otherwise the three-array gathers are used
+            bool tableOk = !c->phaseTable.empty() && c->phaseTable.size() <= 4 && c->prm.gamma > 0.0f;
+            for (size_t k = 0; tableOk && k < c->phaseTable.size(); k++) tableOk = c->phaseTable[k].restDensity > 0.0f;
             const bool packed = c->useHitMask && c->hitMask && tableOk &&
                                 (c->slab ? (s.phase != nullptr && !c->slabPackedOff) : (c->havePhaseIds && !c->staticDirty));
             PackedNbr nbr{packed ? c->nbrA : nullptr, c->nbrB, s.velV, s.origId, c->phaseOfId,
@@ -513,10 +520,11 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
                 if (int rcFold = foldCollisions(c)) return rcFold;
                 hipLaunchKernelGGL(k_full_bound_damp, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, s.acc,
                                    c->blockCollide, c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr,
-                                   lastSub ? 1 : 0);
+                                   lastSub ? 1 : 0, c->counters);
                 c->collideFoldBlocks = nb;
                 break;
             }
+            c->packedValid = false;   // velocities change under the packed neighbour records (record b)
             hipLaunchKernelGGL(k_full_step, dim3(nb), dim3(kBlock), 0, c->stream, n, c->dp.dt, s.velV, s.acc);
             break;
         case SPH_K_BOUND_OBS:
@@ -524,10 +532,11 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
             c->pos3Valid = false;
             if (int rcFold = foldCollisions(c)) return rcFold;
             hipLaunchKernelGGL(k_bound_obs, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, c->blockCollide,
-                               c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr);
+                               c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr, c->counters);
             c->collideFoldBlocks = nb;
             break;
         case SPH_K_VELOCITY_DAMPING:
+            c->packedValid = false;
             hipLaunchKernelGGL(k_velocity_damping, dim3(nb), dim3(kBlock), 0, c->stream, n, s.velV);
             break;
         default:
@@ -555,6 +564,8 @@ int sph_create(sph_ctx** out, int device_id) {
     if (!c) return SPH_E_NOMEM;
     c->device = device_id;
     if (const char* tl = getenv("SPH_HIP_TIMING")) c->timingLevel = atoi(tl);
+    if (const char* ef = getenv("SPH_HIP_EVENT_FENCE")) c->eventFlags = atoi(ef) ? hipEventDefault : hipEventDisableSystemFence;
+    if (const char* ts = getenv("SPH_HIP_TIMING_STRIDE")) c->timingStride = std::max(1, atoi(ts));
     if (const char* hm = getenv("SPH_HIP_HITMASK")) c->useHitMask = atoi(hm) != 0;
     if (const char* xr = getenv("SPH_HIP_XCD_RUN")) c->xcdRunOverride = atoi(xr);
     if (const char* dbg = getenv("SPH_HIP_DEBUG")) c->debug = atoi(dbg) != 0;
@@ -565,7 +576,8 @@ int sph_create(sph_ctx** out, int device_id) {
         return SPH_E_HIP;
     }
     for (int r = 0; r < kTimingRing; r++)
-        for (int k = 0; k < kNumEvents; k++) (void)hipEventCreate(&c->ev[r][k]);
+        // no system-scope fence (cache write-back) when the event completes: it only brackets kernels on this stream
+        for (int k = 0; k < kNumEvents; k++) (void)hipEventCreateWithFlags(&c->ev[r][k], c->eventFlags);
     (void)hipEventCreateWithFlags(&c->packEvent, hipEventDisableTiming);
     if (hipHostMalloc((void**)&c->hostInts, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void**)&c->counters, SPH_CTR_COUNT * sizeof(int)) != hipSuccess ||
@@ -825,7 +837,7 @@ int sph_step_frame(sph_ctx* c, int sub_steps, float time_step) {
     if (c->slotPending[slot] && (rc = harvestSlot(c, slot))) return rc;
     hipEvent_t* ev = c->ev[slot];
     // level 1 times every kTimingStride-th frame, starting with the first one after sph_get_timings
-    const int tl = (c->timingLevel == 1 && c->framesSinceHarvest % kTimingStride != 0) ? 0 : c->timingLevel;
+    const int tl = (c->timingLevel == 1 && c->framesSinceHarvest % c->timingStride != 0) ? 0 : c->timingLevel;
     c->framesSinceHarvest++;
     if (tl >= 1) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
     sph_set_delta_time(c, time_step / (float)sub_steps);                    // SPH.cs:207-208

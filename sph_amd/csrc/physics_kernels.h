@@ -789,18 +789,30 @@ __global__ __launch_bounds__(kBlock) void k_sum_into(const int* __restrict__ blo
     }
 }
 
+// Failure detection (SPH_CTR_NAN): non-finite positions / velocities leaving a boundary pass.  A healthy run never
+// takes the atomic (one per wave that holds such a particle).
+__device__ __forceinline__ void count_non_finite(const float4& p, const float4& v, bool counted, int* __restrict__ counters) {
+    const bool bad = counted && !(__builtin_isfinite(p.x) && __builtin_isfinite(p.y) && __builtin_isfinite(p.z) &&
+                                  __builtin_isfinite(v.x) && __builtin_isfinite(v.y) && __builtin_isfinite(v.z));
+    const unsigned long long m = __ballot(bad);
+    if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(&counters[SPH_CTR_NAN], __popcll(m));
+}
+
 // CS_BoundObs kernel; in slab mode ghost copies are counted by their owner.
 __global__ __launch_bounds__(kBlock) void k_bound_obs(DevParams P, float4* __restrict__ posM,
                                                       float4* __restrict__ velV, int* __restrict__ blockCount,
-                                                      const uint32_t* __restrict__ sortedKeys) {
+                                                      const uint32_t* __restrict__ sortedKeys, int* __restrict__ counters) {
     int s = blockIdx.x * kBlock + threadIdx.x;
-    bool collided = false;
+    bool collided = false, owned = false;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), v = p;
     if (s < P.n) {
-        float4 p = posM[s], v = velV[s];
-        collided = bound_obs_body(P, p, v) && slot_is_owned(P, sortedKeys, s);
+        p = posM[s]; v = velV[s];
+        owned = slot_is_owned(P, sortedKeys, s);
+        collided = bound_obs_body(P, p, v) && owned;
         posM[s] = p;
         velV[s] = v;
     }
+    count_non_finite(p, v, owned, counters);
     block_count(collided, blockCount);
 }
 
@@ -817,19 +829,23 @@ __global__ __launch_bounds__(kBlock) void k_full_bound_damp(DevParams P, float4*
                                                             float4* __restrict__ velV,
                                                             const float4* __restrict__ acc,
                                                             int* __restrict__ blockCount,
-                                                            const uint32_t* __restrict__ sortedKeys, int damp) {
+                                                            const uint32_t* __restrict__ sortedKeys, int damp,
+                                                            int* __restrict__ counters) {
     int s = blockIdx.x * kBlock + threadIdx.x;
-    bool collided = false;
+    bool collided = false, owned = false;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), v = p;
     if (s < P.n) {
-        float4 p = posM[s], v = velV[s];
+        p = posM[s]; v = velV[s];
         const float4 a = acc[s];
         const float hdt = 0.5f * P.dt;
         v.x += hdt * a.x; v.y += hdt * a.y; v.z += hdt * a.z;              // compute:332
-        collided = bound_obs_body(P, p, v) && slot_is_owned(P, sortedKeys, s);
+        owned = slot_is_owned(P, sortedKeys, s);
+        collided = bound_obs_body(P, p, v) && owned;
         if (damp) damp_velocity(v);
         posM[s] = p;
         velV[s] = v;
     }
+    count_non_finite(p, v, owned, counters);
     block_count(collided, blockCount);
 }
 

@@ -103,35 +103,46 @@ def config3(engine, n=1048576, seed=12345, scale=1.6, rocking=True) -> Scene:
     return Scene(sph, time, movers)
 
 
-def config4(engine, n=16777216, seed=12345) -> Scene:
-    """Config 4: 16M two-phase tank (strong scaling); single-GPU form."""
+def config4(engine, n=16777216, seed=12345, cube=(80.0, 120.0, 80.0), box=(78.0, 10.0, 20.0), box_z=12.0) -> Scene:
+    """Config 4: 16M two-phase tank (strong scaling); single-GPU form.  `cube`, `box`, `box_z` shrink the geometry
+    for tests (CONFIG4_SMALL: the same layout -- two boxes spanning the x width side by side in z, static cube, no
+    obstacle, cell 0.25 -- at the same spawn densities, ~700 and ~350 particles per unit^3)."""
     a, b = _split21(n)
-    boxes = [SpawnBox(a, (78, 10, 20), 20, 0.1, 0.2, particleColor=WATER, position=(0, 60, 12)),
-             SpawnBox(b, (78, 10, 20), 10, 0.1, 0.2, particleColor=OIL, position=(0, 60, -12))]
-    cube = Transform(position=(0, 60, 0), localScale=(80, 120, 80))
+    yc = 0.5 * cube[1]
+    boxes = [SpawnBox(a, box, 20, 0.1, 0.2, particleColor=WATER, position=(0, yc, box_z)),
+             SpawnBox(b, box, 10, 0.1, 0.2, particleColor=OIL, position=(0, yc, -box_z))]
+    tank = Transform(position=(0, yc, 0), localScale=cube)
     f = dict(SCENE_COMMON)
-    f.update(gridResolution=320)
-    sph = SPH(engine, **f, surfaceTensionCoefficient=0.01, xsphEpsilon=0.2, boundaryCube=cube, obstacleCollider=None,
+    f.update(gridResolution=int(round(min(cube) / 0.25)))                  # cell size 0.25 (SPH.cs:329); 320 at full size
+    sph = SPH(engine, **f, surfaceTensionCoefficient=0.01, xsphEpsilon=0.2, boundaryCube=tank, obstacleCollider=None,
               spawnBoxes=boxes, seed=seed)
     return Scene(sph, Time(), [])
 
 
-def config5(engine, gpus=1, per_gpu=8388608, seed=12345, block=(80.0, 64.0)) -> Scene:
+# test-size geometry of configs 4 and 5 (tests/test_configs_gpu.py): long enough in x for 4 slabs of >= 2 x 12 ghost
+# planes, spawn densities of the full-size configurations (their blow-up is what sets the ghost width)
+CONFIG4_SMALL = dict(n=48000, cube=(26.0, 12.0, 8.0), box=(24.0, 1.2, 1.6), box_z=1.6)
+CONFIG5_SMALL = dict(per_gpu=12800, block=(8.0, 8.0), height=12.0, box=(7.6, 1.0, 1.6))
+
+
+def config5(engine, gpus=1, per_gpu=8388608, seed=12345, block=(80.0, 64.0), height=96.0, box=None) -> Scene:
     """Config 5: weak scaling, 8,388,608 particles per GPU, G blocks of 80 x 96 x 64 along x.
     `block` = (x, z) extent of one GPU's block; other shapes of the same volume and spawn density are
-    used by locality experiments only."""
+    used by locality experiments only.  `height`, `box` (spawn box size): test-size geometry, CONFIG5_SMALL."""
     G = gpus
     bx, bz = block
     a, b = _split21(per_gpu)
     boxes = []
-    sx, sz = bx - 4.0, 76.0 * 13.0 / (bx - 4.0)          # spawn box footprint of constant area
+    if box is None:
+        box = (bx - 4.0, 8.0, 76.0 * 13.0 / (bx - 4.0))  # spawn box footprint of constant area
+    yc = 0.5 * height
     for g in range(G):
         xc = -0.5 * bx * G + 0.5 * bx + bx * g
-        boxes.append(SpawnBox(a, (sx, 8, sz), 20, 0.1, 0.2, particleColor=WATER, position=(xc, 48, 0.25 * bz)))
-        boxes.append(SpawnBox(b, (sx, 8, sz), 10, 0.1, 0.2, particleColor=OIL, position=(xc, 48, -0.25 * bz)))
-    cube = Transform(position=(0, 48, 0), localScale=(bx * G, 96, bz))
+        boxes.append(SpawnBox(a, box, 20, 0.1, 0.2, particleColor=WATER, position=(xc, yc, 0.25 * bz)))
+        boxes.append(SpawnBox(b, box, 10, 0.1, 0.2, particleColor=OIL, position=(xc, yc, -0.25 * bz)))
+    cube = Transform(position=(0, yc, 0), localScale=(bx * G, height, bz))
     f = dict(SCENE_COMMON)
-    f.update(gridResolution=int(round(min(bx * G, 96.0, bz) / 0.25)))      # cell size 0.25 (SPH.cs:329)
+    f.update(gridResolution=int(round(min(bx * G, height, bz) / 0.25)))     # cell size 0.25 (SPH.cs:329)
     sph = SPH(engine, **f, surfaceTensionCoefficient=0.01, xsphEpsilon=0.2, boundaryCube=cube, obstacleCollider=None,
               spawnBoxes=boxes, seed=seed)
     return Scene(sph, Time(), [])

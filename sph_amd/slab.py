@@ -461,6 +461,22 @@ class SlabEngine:
         self.port.upload_owned(owned)
         self.n = owned.shape[0]
 
+    def resync(self, aos, phase_of_id):
+        """Lock-step parity against a single-domain run (tests): replace the distributed state by `aos`, the 72-byte
+        records of ALL particles in global id order (phase_of_id: their spawn box).  Every rank keeps the rows of its
+        owned planes under the current cuts; the ghosts come with the next frame's exchange, as after the initial
+        distribution.  No communication."""
+        aos = np.asarray(aos, dtype=np.float32).reshape(-1, abi.PARTICLE_FLOATS)
+        plane = self._planes(aos[:, 0])
+        m = (plane >= self.own[0]) & (plane < self.own[1])
+        ids = np.flatnonzero(m).astype(np.uint32)
+        if ids.shape[0] > self._capacity:
+            raise RuntimeError(f"resync: {ids.shape[0]} particles exceed this slab's capacity of {self._capacity}")
+        self.port.upload_owned(abi.records_from_aos(aos[m], ids, np.asarray(phase_of_id)[m]))
+        self.n = int(ids.shape[0])
+        self.e.n = self.n
+        self._primed = False
+
     def set_delta_time(self, dt):
         self.e.set_delta_time(dt)
 
@@ -578,8 +594,15 @@ def bench_main(args, rank, local_rank, world):
     # Rehearsal on a one-GPU box: SPH_BENCH_BACKEND=gloo SPH_BENCH_SHARE_GPU=1 runs all ranks on
     # device 0 with host-staged messages.  The real run is one rank per GPU over RCCL.
     backend = os.environ.get("SPH_BENCH_BACKEND", "nccl")
-    if os.environ.get("SPH_BENCH_SHARE_GPU") == "1":
-        local_rank = 0
+    share = os.environ.get("SPH_BENCH_SHARE_GPU")
+    rehearsal = None
+    if share is None and torch.cuda.device_count() < world:
+        # fewer GPUs than ranks (a one-GPU box): a functional rehearsal, said so in the JSON line -- RCCL refuses
+        # two ranks on one device, so the messages are host-staged over gloo
+        share, backend = "1", "gloo"
+    if share == "1":
+        rehearsal = f"{world} ranks share {torch.cuda.device_count()} GPU(s), host-staged messages ({backend}): functional rehearsal, not a scaling measurement"
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if not dist.is_initialized():
         if backend == "nccl":
@@ -667,6 +690,16 @@ def bench_main(args, rank, local_rank, world):
         sub = sc.sph.subSteps
         n_local = se.n
         achieved = 64.0 * n_local / (force_ms * 1e-3) / 1e9
+        # counters are per GPU: the committed one-GPU PMC pass of the same per-GPU load (config 5, G = 1) at this
+        # warm-up, if there is one; the CPU baseline is timed on the one-GPU leg only (bench.py --gpus 1) and quoted
+        from . import benchutil as _bench
+        run = None if strong else _bench.counter_run("config5", per_gpu, args.warmup)
+        cpu = None
+        try:
+            cpu = dict(json.load(open(os.path.join(_bench.ROOT, "profiles", "cpu_baseline_1gpu.json"))))
+            cpu["sample"] = "NOT re-timed in this run: " + cpu.get("sample", "") + " (one-GPU leg, profiles/cpu_baseline_1gpu.json)"
+        except Exception:
+            cpu = None
         print(json.dumps({
             "metric": "particle-updates/sec", "value": n_total * sub * args.steps / dt, "unit": "particle-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -677,6 +710,8 @@ def bench_main(args, rank, local_rank, world):
                                    f"two-phase, x-slabs with "
                                    f"{ghost} ghost planes, one neighbour message per face per frame ({backend} send/recv)",
                        "particles": n_total, "sub_steps": sub, "parallelism": f"slab{world}",
+                       "world_size": dist.get_world_size(), "backend": dist.get_backend(), "rehearsal": rehearsal,
+                       "self_launched": os.environ.get("SPH_BENCH_SELF_LAUNCHED") == "1",
                        "halo_violations": viol, "bin_overflow_cells": overflow,
                        "rebalance_every": se.rebalance_every, "recuts": se.recuts,
                        "exchange_overlapped": se.overlap, "band_fraction_rank0": round(se.band_fraction, 4),
@@ -686,9 +721,13 @@ def bench_main(args, rank, local_rank, world):
                            "value": solo, "workload": f"config5, {per_gpu} particles, one GPU, no slabs (slowest of the "
                                                       f"{world} GPUs, run concurrently)",
                            "weak_scaling_efficiency": n_total * sub * args.steps / dt / (world * solo)}},
-            "roofline": {"bound": "hbm", "kernel": "k_force_xsph_hits (CS_ForceXSPH), slowest rank", "achieved": achieved,
-                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                         "avg_launch_ms": force_ms},
+            "roofline": {"bound": "hbm", "measured_limiter": _bench.MEASURED_LIMITER,
+                         "kernel": "k_force_xsph_hits (CS_ForceXSPH), slowest rank", "achieved": achieved,
+                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": _bench.measured_traffic(run, "k_force_xsph_hits"),
+                         "traffic_from": None if run is None else f"one GPU, same per-GPU load, warmup {run['warmup']} ({run.get('source', 'profiles/')})",
+                         "alg_bytes_per_particle": 64, "particles_rank0": n_local, "avg_launch_ms": force_ms},
+            "cpu_baseline": cpu,
             "stage_ms_rank0": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
         }))
     eng.destroy()

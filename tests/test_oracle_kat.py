@@ -189,3 +189,15 @@ def test_xsph_jacobi_vs_inplace_differ_but_little(ora):
     va, vb = a.download_particles()[:, 3:6], b.download_particles()[:, 3:6]
     assert not np.array_equal(va, vb)
     assert np.abs(va - vb).max() < 0.2 * np.abs(va).max()
+
+
+def test_oracle_is_clean_under_asan_and_ubsan():
+    """SURVEY section 5 (race detection / sanitizers): the oracle and a driver that walks its memory-indexing branches
+    (bin overflow, particles outside the grid on every side, NaN, OBB / AABB / sphere, grid resizes) built with
+    -fsanitize=address,undefined; any report fails `make -C oracle asan`."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count(" ok") >= 2 and "FAILED" not in r.stdout
