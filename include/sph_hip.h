@@ -277,6 +277,16 @@ int  sph_slab_pack_wait(sph_ctx* ctx, int* n_left, int* n_right, int* n_band_wor
  * messages carry whatever changes hands.  The driver must keep every new face, plus the ghost width, inside the
  * two slabs that were adjacent to the old face (sph_amd/slab.py: SlabEngine.rebalance). */
 int  sph_slab_plane_counts(sph_ctx* ctx, int32_t* counts, int n_planes);
+/* sph_slab_plane_counts for callers that CANNOT ALLOCATE (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  No counterpart in the reference.  Same result as sph_slab_plane_counts (also available
+ * outside slab mode: n_planes = the grid's x resolution), but the per-plane counters the kernel accumulates into live
+ * in a static device array of the library (SPH_PLANE_COUNTS_MAX ints = 32 KiB per GPU, held until the process ends)
+ * instead of a buffer allocated on demand: the call makes no hipMalloc / hipFree.  n_planes > SPH_PLANE_COUNTS_MAX is
+ * rejected (SPH_E_INVALID).  `counts` may be device memory of the ctx's GPU or host memory (pinned host memory if the
+ * caller also forbids the runtime's own staging of pageable copies).  Every call on a GPU shares that GPU's array:
+ * calls that overlap on one GPU (two ctxs on the same device driven from two threads) race.  Synchronises. */
+#define SPH_PLANE_COUNTS_MAX 8192
+int  sph_slab_plane_counts_noalloc(sph_ctx* ctx, int32_t* counts, int n_planes);
 /* Current local particle count (owned + ghosts). */
 int  sph_particle_count(sph_ctx* ctx, int* n);
 

@@ -22,6 +22,7 @@ KERNEL_NAMES = ["CS_Clear", "CS_ClearGrid", "CS_BuildGrid", "CS_DensityPressure"
 
 CTR_COLLISIONS, CTR_BIN_OVERFLOW, CTR_OUT_OF_GRID, CTR_MAX_PLANE_SHIFT, CTR_BAND_MISSES, CTR_NAN = range(6)
 SLAB_RECORD_BYTES = 64
+PLANE_COUNTS_MAX = 8192      # SPH_PLANE_COUNTS_MAX
 
 # every symbol include/sph_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -32,7 +33,7 @@ EXPORTS = [
     "sph_download_grid", "sph_download_neighbors", "sph_get_timings", "sph_device_pointer",
     "sph_get_stream", "sph_slab_configure", "sph_slab_reserve", "sph_slab_upload", "sph_slab_download",
     "sph_slab_pack", "sph_slab_rebuild", "sph_slab_arm_pack", "sph_slab_pack_wait", "sph_slab_plane_counts",
-    "sph_particle_count",
+    "sph_slab_plane_counts_noalloc", "sph_particle_count",
 ]
 
 
@@ -173,6 +174,7 @@ def load_library() -> C.CDLL:
     lib.sph_slab_arm_pack.argtypes = [vp, ip, ip, ip, vp, ip, vp, ip]
     lib.sph_slab_pack_wait.argtypes = [vp, C.POINTER(ip), C.POINTER(ip), C.POINTER(ip)]
     lib.sph_slab_plane_counts.argtypes = [vp, vp, ip]
+    lib.sph_slab_plane_counts_noalloc.argtypes = [vp, vp, ip]
     lib.sph_particle_count.argtypes = [vp, C.POINTER(ip)]
     for name in EXPORTS:
         fn = getattr(lib, name)
@@ -340,6 +342,16 @@ class Engine:
     def slab_plane_counts(self, rx_local) -> np.ndarray:
         out = np.zeros(rx_local, dtype=np.int32)
         self._ck(self.lib.sph_slab_plane_counts(self.h, _ptr(out), rx_local))
+        return out
+
+    def slab_plane_counts_noalloc(self, rx_local, out=None) -> np.ndarray:
+        """The variant that allocates nothing on the device (static scratch, at most PLANE_COUNTS_MAX planes).  `out`:
+        an int32 array to fill (host), or an int = device pointer of rx_local int32."""
+        if isinstance(out, int):
+            self._ck(self.lib.sph_slab_plane_counts_noalloc(self.h, C.c_void_p(out), rx_local))
+            return None
+        out = np.zeros(rx_local, dtype=np.int32) if out is None else out
+        self._ck(self.lib.sph_slab_plane_counts_noalloc(self.h, _ptr(out), rx_local))
         return out
 
     def particle_count(self) -> int:

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -32,8 +33,14 @@ struct DevBuf {
 
 }  // namespace
 
+// Scratch of sph_slab_plane_counts_noalloc: per-plane counters, one copy of the array per GPU the library runs on.
+// In host code this NAME is only a handle for hipGetSymbolAddress; the device address is resolved once per device
+// (planeScratchFor) and only that pointer is ever passed to kernels, memsets and copies.
+static __device__ __align__(256) int scratch[SPH_PLANE_COUNTS_MAX];
+
 struct sph_ctx {
     int device = 0;
+    int* planeScratch = nullptr;      // this GPU's copy of `scratch` (device address)
     hipStream_t stream = nullptr;
     std::string err;
 
@@ -135,6 +142,25 @@ struct sph_ctx {
 };
 
 namespace {
+
+// Device address of `scratch` on `device` (which must be current): resolved once per device, then cached.
+constexpr int kMaxDevices = 64;
+std::mutex g_scratchMutex;
+int* g_scratchPtr[kMaxDevices] = {};
+
+hipError_t planeScratchFor(int device, int** out) {
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratchMutex);
+    if (!g_scratchPtr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratchPtr[device] = (int*)p;
+    }
+    *out = g_scratchPtr[device];
+    return hipSuccess;
+}
 
 int fail(sph_ctx* c, int code, const char* fmt, ...) {
     char buf[512];
@@ -573,6 +599,11 @@ int sph_create(sph_ctx** out, int device_id) {
     if (const char* gf = getenv("SPH_HIP_GHOST_FORCE")) c->skipGhostForce = atoi(gf) == 0;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
+        return SPH_E_HIP;
+    }
+    if (planeScratchFor(device_id, &c->planeScratch) != hipSuccess) {   // device_id is current here
+        (void)hipGetLastError();
+        sph_destroy(c);
         return SPH_E_HIP;
     }
     for (int r = 0; r < kTimingRing; r++)
@@ -1279,6 +1310,30 @@ int sph_slab_plane_counts(sph_ctx* c, int32_t* counts, int n_planes) {
                        (const int*)c->cellCum, c->rx, rows, c->planeCounts);
     CHECK_LAUNCH(c);
     HIP_TRY(c, hipMemcpyAsync(counts, c->planeCounts, sizeof(int) * (size_t)n_planes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+// The variant of sph_slab_plane_counts that allocates nothing: the counters are this GPU's copy of the static
+// `scratch` array (c->planeScratch, resolved in sph_create).  The array keeps the last call's contents, so the part in
+// use is cleared first.
+int sph_slab_plane_counts_noalloc(sph_ctx* c, int32_t* counts, int n_planes) {
+    if (!c) return SPH_E_INVALID;
+    if (n_planes > SPH_PLANE_COUNTS_MAX)
+        return fail(c, SPH_E_INVALID, "%d planes exceed the static scratch of %d planes (use sph_slab_plane_counts)", n_planes,
+                    SPH_PLANE_COUNTS_MAX);
+    if (!counts || n_planes <= 0 || n_planes != c->rx)
+        return fail(c, SPH_E_INVALID, "expected %d plane counts (the local x resolution), got %d", c->rx, n_planes);
+    if (!c->gridValid) return fail(c, SPH_E_STATE, "plane counts need the grid of the last frame (call before sph_slab_rebuild)");
+    if (!c->planeScratch) return fail(c, SPH_E_STATE, "static scratch not resolved on GPU %d", c->device);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int* const ptr = c->planeScratch;
+    HIP_TRY(c, hipMemsetAsync(ptr, 0, sizeof(int) * (size_t)n_planes, c->stream));
+    const long long rows = c->tableCells / c->rx;
+    hipLaunchKernelGGL(k_plane_counts, dim3((unsigned)((rows + kPlaneRows - 1) / kPlaneRows)), dim3(kBlock), 0, c->stream,
+                       (const int*)c->cellCum, c->rx, rows, ptr);
+    CHECK_LAUNCH(c);
+    HIP_TRY(c, hipMemcpyAsync(counts, ptr, sizeof(int) * (size_t)n_planes, hipMemcpyDefault, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SPH_OK;
 }
