@@ -186,9 +186,8 @@ def main(argv=None):
         "config5narrow": lambda e: scenes.config5(e, gpus=1, per_gpu=args.particles or 8388608, block=(20.0, 256.0)),
     }
     builder = builders[wl]
-    # kernel times come from hipEvents the library records on ITS stream; a short timed region (the driver's 20
-    # frames) records them on every frame, a long one on every 4th (an event costs stream time)
-    os.environ.setdefault("SPH_HIP_TIMING_STRIDE", "1" if args.steps <= 32 else "4")
+    # kernel times: start / stop events the library attaches to its own launches, on its own stream, on every timed
+    # frame (they add no packet to the stream: sph_timings in include/sph_hip.h)
     eng = abi.Engine(local_rank)
     sc = builder(eng)
     sc.sph.use_step_frame = True
@@ -209,7 +208,12 @@ def main(argv=None):
         sc.frame()
     eng.synchronize()
     dt = time.perf_counter() - t0
-    tm = eng.get_timings()                # hipEvents on the engine's stream, averaged over the timed frames
+    try:
+        tm = eng.get_timings()            # launch-attached events on the engine's stream, averaged over the timed frames
+    except abi.SphError:                  # SPH_HIP_TIMING=0: no kernel times, the line still carries the throughput
+        tm = {k: float("nan") for k in ("build_grid_ms", "half_step_ms", "density_ms", "force_ms", "full_step_ms",
+                                        "bound_obs_ms", "damping_ms", "frame_ms")}
+        tm["frames"] = 0
     overflow = eng.read_counter(abi.CTR_BIN_OVERFLOW)
     non_finite = eng.read_counter(abi.CTR_NAN)
 

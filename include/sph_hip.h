@@ -120,14 +120,15 @@ enum sph_counter {
 
 typedef struct sph_ctx sph_ctx;
 
-/* Per-stage device time in milliseconds (hipEvents on the ctx's stream), AVERAGED over the
- * sph_step_frame calls since the previous sph_get_timings call (which resets the average).
- * With subSteps > 1 the sub-step stages are those of the last sub-step.  Every recorded event costs a
- * few microseconds of stream time, so by default (SPH_HIP_TIMING=1) only five are recorded per frame,
- * and only on every 4th frame (starting with the first frame after sph_get_timings): build_grid_ms then
- * includes the half step and full_step_ms is the fused tail (full step + boundary + damping);
- * SPH_HIP_TIMING=2 records every stage boundary of every frame, SPH_HIP_TIMING=0 none.  `frames` is
- * the number of frames that were timed. */
+/* Per-stage device time in milliseconds, AVERAGED over the timed sph_step_frame calls since the previous
+ * sph_get_timings call (which resets the average).  The times are those of the dispatch packets themselves: start / stop
+ * events attached to the frame's own launches (hipExtLaunchKernelGGL), so a timed frame enqueues exactly what an untimed
+ * one does (a hipEventRecord between kernels is a barrier packet of its own, ~5 us of stream time each).
+ * build_grid_ms runs from the first launch of the grid build to the end of the reorder (which also does the first half
+ * step); full_step_ms is the fused tail (full step + boundary + damping); frame_ms from the first launch to the last;
+ * half_step_ms / bound_obs_ms / damping_ms are 0 (those stages are fused).  With subSteps > 1 the sub-step stages are
+ * those of the last sub-step.  SPH_HIP_TIMING=0 records nothing; SPH_HIP_TIMING_STRIDE=k times every k-th frame
+ * (default 1).  `frames` is the number of frames that were timed. */
 typedef struct sph_timings {
     float build_grid_ms;   /* hash + counting sort by cell + reorder             */
     float half_step_ms;

@@ -4,6 +4,7 @@
 // Assets/SPH.cs (FindKernel / Set* / SetBuffer / Dispatch / SetData / GetData / Release) is done
 // here over HIP.  No CPU fallback exists: without a gfx950 device sph_create fails.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -22,9 +23,12 @@ using namespace sph;
 
 namespace {
 
-constexpr int kNumEvents = 8;    // stage boundaries of one frame
+constexpr int kNumEvents = 8;    // start / stop of the four timed spans of a frame
+// Kernel times come from the dispatch packets themselves: hipExtLaunchKernelGGL attaches a start and a stop event to
+// a launch, so timing adds no packet to the stream (a hipEventRecord between two kernels is a barrier packet of its own
+// and cost ~5 us of stream time each: 6 % of a 0.44 ms frame with five of them).
+enum { E_GRID0 = 0, E_GRID1, E_DENS0, E_DENS1, E_FORCE0, E_FORCE1, E_TAIL0, E_TAIL1 };
 constexpr int kTimingRing = 32;  // frames whose events may be outstanding
-constexpr int kTimingStride = 4;  // SPH_HIP_TIMING=1: frames between timed frames (an event costs stream time); SPH_HIP_TIMING_STRIDE overrides
 
 struct DevBuf {
     void* p = nullptr;
@@ -132,10 +136,14 @@ struct sph_ctx {
     // lazily (when a slot is reused, or in sph_get_timings)
     hipEvent_t ev[kTimingRing][kNumEvents] = {};
     bool slotPending[kTimingRing] = {};
+    unsigned slotRecorded[kTimingRing] = {};   // bit k: ev[slot][k] was attached to a launch (an empty slab launches nothing)
+    hipEvent_t* tev = nullptr;          // events of the frame being enqueued, null = this frame is not timed
+    unsigned* tevMask = nullptr;
+    bool tevSub = false;                // the sub-step being enqueued is the timed one (the last)
     int ringNext = 0;
     double stageSum[kNumEvents] = {};   // ms; [7] = whole frame
-    int timingLevel = 1;                // 0 none, 1 frame + density + force on sampled frames (default), 2 every stage
-    int timingStride = kTimingStride;   // level 1: every this-many-th frame is timed
+    int timingLevel = 1;                // 0 none, 1 every timingStride-th frame (default), 2 every frame
+    int timingStride = 1;               // level 1: every this-many-th frame is timed (SPH_HIP_TIMING_STRIDE)
     unsigned eventFlags = hipEventDisableSystemFence;   // SPH_HIP_EVENT_FENCE=1: default events (A/B)
     int framesSinceHarvest = 0;         // level 1 records events on every kTimingStride-th frame only
     int framesTimed = 0;
@@ -181,6 +189,21 @@ int fail(sph_ctx* c, int code, const char* fmt, ...) {
     } while (0)
 
 #define CHECK_LAUNCH(c) HIP_TRY(c, hipGetLastError())
+
+// Launch on the ctx's stream; e0 / e1 >= 0: attach ev[e0] as the start and / or ev[e1] as the stop event of this launch
+// when the frame is timed.
+#define LAUNCH_T(c, e0, e1, kernel, grid, ...)                                                                        \
+    do {                                                                                                              \
+        hipEvent_t s_ = ((c)->tev && (e0) >= 0) ? (c)->tev[(e0) < 0 ? 0 : (e0)] : (hipEvent_t) nullptr;                \
+        hipEvent_t t_ = ((c)->tev && (e1) >= 0) ? (c)->tev[(e1) < 0 ? 0 : (e1)] : (hipEvent_t) nullptr;                \
+        if (s_ || t_) {                                                                                               \
+            hipExtLaunchKernelGGL(kernel, grid, dim3(kBlock), 0, (c)->stream, s_, t_, 0, __VA_ARGS__);                \
+            if (s_) *(c)->tevMask |= 1u << ((e0) < 0 ? 0 : (e0));                                                     \
+            if (t_) *(c)->tevMask |= 1u << ((e1) < 0 ? 0 : (e1));                                                     \
+        } else {                                                                                                      \
+            hipLaunchKernelGGL(kernel, grid, dim3(kBlock), 0, (c)->stream, __VA_ARGS__);                              \
+        }                                                                                                             \
+    } while (0)
 
 inline int blocksFor(long long n) { return (int)((n + kBlock - 1) / kBlock); }
 
@@ -309,26 +332,25 @@ int readInts(sph_ctx* c, const int* dev, int n, int* out) {
 
 int harvestSlot(sph_ctx* c, int slot) {
     hipEvent_t* ev = c->ev[slot];
-    HIP_TRY(c, hipEventSynchronize(ev[7]));
+    const unsigned rec = c->slotRecorded[slot];
+    c->slotPending[slot] = false;
+    if (!rec) return SPH_OK;                                  // an empty slab: nothing was launched
+    for (int k = kNumEvents - 1; k >= 0; k--)
+        if (rec & (1u << k)) { HIP_TRY(c, hipEventSynchronize(ev[k])); break; }
     auto span = [&](int a, int b, int into) -> int {
+        if (!(rec & (1u << a)) || !(rec & (1u << b))) return SPH_OK;
         float t = 0;
         HIP_TRY(c, hipEventElapsedTime(&t, ev[a], ev[b]));
         c->stageSum[into] += t;
         return SPH_OK;
     };
-    int rc = SPH_OK;
-    if (c->timingLevel >= 2) {
-        for (int k = 0; k < 7 && !rc; k++) rc = span(k, k + 1, k);
-    } else {                       // level 1: grid build + half step share one span
-        rc = span(0, 2, 0);
-        if (!rc) rc = span(2, 3, 2);
-        if (!rc) rc = span(3, 4, 3);
-        if (!rc) rc = span(4, 7, 4);
-    }
-    if (!rc) rc = span(0, 7, 7);
+    int rc = span(E_GRID0, E_GRID1, 0);                       // grid build incl. the fused first half step
+    if (!rc) rc = span(E_DENS0, E_DENS1, 2);
+    if (!rc) rc = span(E_FORCE0, E_FORCE1, 3);
+    if (!rc) rc = span(E_TAIL0, E_TAIL1, 4);                  // fused tail: full step + boundary (+ damping)
+    if (!rc) rc = span(E_GRID0, E_TAIL1, 7);                  // whole frame, first launch to last
     if (rc) return rc;
     c->framesTimed++;
-    c->slotPending[slot] = false;
     return SPH_OK;
 }
 
@@ -356,8 +378,8 @@ int clearGrid(sph_ctx* c, bool resetBuildCounters = false) {
     // T[-4 .. cells padded to int4): zero = "no particle in any cell"
     const size_t padded = ((size_t)c->tableCells + 3) / 4 * 4 + 4;
     const long long n4 = (long long)(padded / 4);
-    hipLaunchKernelGGL(k_clear_table, dim3((unsigned)((n4 + kBlock * 4 - 1) / (kBlock * 4))), dim3(kBlock), 0, c->stream,
-                       (int4*)c->cumBase, n4, resetBuildCounters ? c->counters : (int*)nullptr);
+    LAUNCH_T(c, resetBuildCounters ? E_GRID0 : -1, -1, k_clear_table, dim3((unsigned)((n4 + kBlock * 4 - 1) / (kBlock * 4))),
+             (int4*)c->cumBase, n4, resetBuildCounters ? c->counters : (int*)nullptr);
     CHECK_LAUNCH(c);
     c->gridValid = false;
     c->maskValid = false;
@@ -420,8 +442,8 @@ int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
     // velocities of the new order go to the set that does NOT hold the current ones
     dst.velV = c->set[1 - c->velCur].velV;
     if (fuseHalfStep)   // sph_step_frame: rank + reorder + first CS_VvHalfStep in one pass
-        hipLaunchKernelGGL(k_rank_move<true>, dim3(nbNew), dim3(kBlock), 0, c->stream, c->sortedKeys, perm, c->sid, nNew, c->cap,
-                           c->dp.dt, c->cellCum, src, dst, c->counters, c->pos3);
+        LAUNCH_T(c, -1, E_GRID1, k_rank_move<true>, dim3(nbNew), c->sortedKeys, perm, c->sid, nNew, c->cap, c->dp.dt, c->cellCum, src,
+                 dst, c->counters, c->pos3);
     else
         hipLaunchKernelGGL(k_rank_move<false>, dim3(nbNew), dim3(kBlock), 0, c->stream, c->sortedKeys, perm, c->sid, nNew, c->cap,
                            c->dp.dt, c->cellCum, src, dst, c->counters, (float*)nullptr);
@@ -487,14 +509,15 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
             for (size_t k = 1; uniform && k < c->phaseTable.size(); k++) uniform = c->phaseTable[k].mass == c->phaseTable[0].mass;
             uint32_t* const mask = c->useHitMask ? c->hitMask : (uint32_t*)nullptr;
             const uint32_t* const skeys = c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr;
+            const int d0 = c->tevSub ? E_DENS0 : -1, d1 = c->tevSub ? E_DENS1 : -1;
             if (uniform)
-                hipLaunchKernelGGL(k_density_pressure_rows<true>, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.rho0,
-                                   s.rhoP, c->cellCum, c->counters, mask, c->capacity, nbr, skeys, c->blockInts,
-                                   (const float*)c->pos3, c->phaseTable[0].mass);
+                LAUNCH_T(c, d0, d1, k_density_pressure_rows<true>, dim3(nb), c->dp, (const float4*)s.posM, (const float*)s.rho0, s.rhoP,
+                         (const int*)c->cellCum, (const int*)c->counters, mask, c->capacity, nbr, skeys, c->blockInts,
+                         (const float*)c->pos3, c->phaseTable[0].mass);
             else
-                hipLaunchKernelGGL(k_density_pressure_rows<false>, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.rho0,
-                                   s.rhoP, c->cellCum, c->counters, mask, c->capacity, nbr, skeys, c->blockInts,
-                                   (const float*)nullptr, 0.0f);
+                LAUNCH_T(c, d0, d1, k_density_pressure_rows<false>, dim3(nb), c->dp, (const float4*)s.posM, (const float*)s.rho0, s.rhoP,
+                         (const int*)c->cellCum, (const int*)c->counters, mask, c->capacity, nbr, skeys, c->blockInts,
+                         (const float*)nullptr, 0.0f);
             if (c->slab)
                 hipLaunchKernelGGL(k_slab_shift_reduce, dim3(1), dim3(kBlock), 0, c->stream, c->blockInts, nb,
                                    c->counters + SPH_CTR_MAX_PLANE_SHIFT);
@@ -504,6 +527,8 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
         }
         case SPH_K_FORCE_XSPH: {
             float4* velOut = c->set[1 - c->velCur].velV;
+            // timed sub-step: the span runs from the first launch (band workgroups, or the only one) to the last
+            const int f0 = (c->tevSub && wgPhase != 0) ? E_FORCE0 : -1, f1 = (c->tevSub && wgPhase != 1) ? E_FORCE1 : -1;
             if (c->debug) {
                 const int variant = !c->maskValid ? 0 : (c->packedValid && (c->slab ? !c->slabPackedOff : !c->staticDirty)) ? 2 : 1;
                 if (variant != c->lastForceVariant) {
@@ -520,16 +545,18 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
                     v[k] = c->phaseTable[k].viscosity;
                 }
                 const PhaseConsts ph{m[0], m[1], m[2], m[3], v[0], v[1], v[2], v[3]};
-                hipLaunchKernelGGL(k_force_xsph_hits<true>, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV,
-                                   s.rhoP, s.acc, velOut, c->cellCum, c->counters, c->hitMask, c->capacity, c->nbrA, c->nbrB, ph,
-                                   c->slab ? (const int*)c->phaseMismatch : (const int*)nullptr, fused ? 1 : 0);
+                LAUNCH_T(c, f0, f1, k_force_xsph_hits<true>, dim3(nb), c->dp, (const float4*)s.posM, (const float4*)s.velV,
+                         (const float2*)s.rhoP, s.acc, velOut, (const int*)c->cellCum, (const int*)c->counters,
+                         (const uint32_t*)c->hitMask, c->capacity, (const float4*)c->nbrA, (const float4*)c->nbrB, ph,
+                         c->slab ? (const int*)c->phaseMismatch : (const int*)nullptr, fused ? 1 : 0);
             } else if (c->maskValid) {
-                hipLaunchKernelGGL(k_force_xsph_hits<false>, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV,
-                                   s.rhoP, s.acc, velOut, c->cellCum, c->counters, c->hitMask, c->capacity, (const float4*)nullptr,
-                                   (const float4*)nullptr, PhaseConsts{}, (const int*)nullptr, fused ? 1 : 0);
+                LAUNCH_T(c, f0, f1, k_force_xsph_hits<false>, dim3(nb), c->dp, (const float4*)s.posM, (const float4*)s.velV,
+                         (const float2*)s.rhoP, s.acc, velOut, (const int*)c->cellCum, (const int*)c->counters,
+                         (const uint32_t*)c->hitMask, c->capacity, (const float4*)nullptr, (const float4*)nullptr, PhaseConsts{},
+                         (const int*)nullptr, fused ? 1 : 0);
             } else {
-                hipLaunchKernelGGL(k_force_xsph_rows, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV,
-                                   s.rhoP, s.acc, velOut, c->cellCum, c->counters, fused ? 1 : 0);
+                LAUNCH_T(c, f0, f1, k_force_xsph_rows, dim3(nb), c->dp, (const float4*)s.posM, (const float4*)s.velV,
+                         (const float2*)s.rhoP, s.acc, velOut, (const int*)c->cellCum, (const int*)c->counters, fused ? 1 : 0);
             }
             if (wgPhase != 1) c->velCur = 1 - c->velCur;
             break;
@@ -544,9 +571,9 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
                 c->maskValid = false;
                 c->pos3Valid = false;
                 if (int rcFold = foldCollisions(c)) return rcFold;
-                hipLaunchKernelGGL(k_full_bound_damp, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.velV, s.acc,
-                                   c->blockCollide, c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr,
-                                   lastSub ? 1 : 0, c->counters);
+                LAUNCH_T(c, c->tevSub ? E_TAIL0 : -1, c->tevSub ? E_TAIL1 : -1, k_full_bound_damp, dim3(nb), c->dp, s.posM, s.velV,
+                         (const float4*)s.acc, c->blockCollide, c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr,
+                         lastSub ? 1 : 0, c->counters);
                 c->collideFoldBlocks = nb;
                 break;
             }
@@ -866,17 +893,20 @@ int sph_step_frame(sph_ctx* c, int sub_steps, float time_step) {
     if ((rc = applyPhaseTable(c))) return rc;                               // SPH.cs:198
     const int slot = c->ringNext;
     if (c->slotPending[slot] && (rc = harvestSlot(c, slot))) return rc;
-    hipEvent_t* ev = c->ev[slot];
-    // level 1 times every kTimingStride-th frame, starting with the first one after sph_get_timings
-    const int tl = (c->timingLevel == 1 && c->framesSinceHarvest % c->timingStride != 0) ? 0 : c->timingLevel;
+    // every timingStride-th frame is timed, starting with the first one after sph_get_timings; the events ride on the
+    // frame's own launches (LAUNCH_T), so a timed frame enqueues exactly what an untimed one does
+    const bool timed = c->timingLevel >= 1 && (c->timingLevel >= 2 || c->framesSinceHarvest % c->timingStride == 0);
     c->framesSinceHarvest++;
-    if (tl >= 1) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
+    c->slotRecorded[slot] = 0;
+    c->tev = timed ? c->ev[slot] : nullptr;
+    c->tevMask = &c->slotRecorded[slot];
+    c->tevSub = false;
+    struct Untime { sph_ctx* c; ~Untime() { c->tev = nullptr; c->tevSub = false; } } untime{c};   // also on the error returns
     sph_set_delta_time(c, time_step / (float)sub_steps);                    // SPH.cs:207-208
     // SPH.cs:201 + 204: CS_ClearGrid is the first step of the grid build here; the state reorder at
     // its end also does the first sub-step's CS_VvHalfStep
     c->dp.n = c->n;
     if ((rc = buildGrid(c, true))) return rc;
-    if (tl >= 2) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     // slab mode, sph_slab_arm_pack: this frame packs its own face messages (see slab_kernels.h)
     const sph_ctx::ArmedPack ap = c->armedPack;
     c->armedPack.armed = false;
@@ -902,9 +932,8 @@ int sph_step_frame(sph_ctx* c, int sub_steps, float time_step) {
     for (int s = 0; s < sub_steps; s++) {                                   // SPH.cs:210-219
         const bool last = s == sub_steps - 1;
         if (s > 0 && (rc = dispatchKernel(c, SPH_K_VV_HALF_STEP))) return rc;
-        if (last && tl >= 1) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
+        c->tevSub = last;                                                   // the sub-step stages reported are the last sub-step's
         if ((rc = dispatchKernel(c, SPH_K_DENSITY_PRESSURE))) return rc;
-        if (last && tl >= 1) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
         if (last && split) {
             if ((rc = dispatchKernel(c, SPH_K_FORCE_XSPH, true, last, 1))) return rc;       // band workgroups
             StateSet st = c->set[c->cur];
@@ -925,15 +954,9 @@ int sph_step_frame(sph_ctx* c, int sub_steps, float time_step) {
             c->bandSendLo = ap.leftBelow; c->bandSendHi = ap.rightFrom;
         }
         if ((rc = dispatchKernel(c, SPH_K_FORCE_XSPH, true, last, last && split ? 0 : -1))) return rc;
-        if (last && tl >= 1) HIP_TRY(c, hipEventRecord(ev[4], c->stream));
         if ((rc = dispatchKernel(c, SPH_K_VV_FULL_STEP, true, last))) return rc;
-        if (last && tl >= 2) {
-            HIP_TRY(c, hipEventRecord(ev[5], c->stream));
-            HIP_TRY(c, hipEventRecord(ev[6], c->stream));
-        }
     }
-    if (tl >= 1) {
-        HIP_TRY(c, hipEventRecord(ev[7], c->stream));
+    if (timed) {
         c->slotPending[slot] = true;
         c->ringNext = (slot + 1) % kTimingRing;
     }
