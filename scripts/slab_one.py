@@ -9,7 +9,7 @@ dist.init_process_group("gloo", rank=0, world_size=1)
 eng = abi.Engine(0)
 port = slab.DevicePort(eng, 0, msg_capacity=max(n // 4, 65536))
 comm = slab.NeighbourComm(0, 1, torch.device("cuda", 0), backend="gloo")
-se = slab.SlabEngine(port, comm, 0, 1, ghost_planes=8)
+se = slab.SlabEngine(port, comm, 0, 1, ghost_planes=int(os.environ.get("GHOST", "8")), overlap=os.environ.get("OVERLAP", "0") == "1")
 sc = scenes.config5(se, gpus=1, per_gpu=n)
 sc.sph.use_step_frame = True
 sc.start()
@@ -27,7 +27,7 @@ def timed(name, fn):
     def w(*a, **k):
         t = _t.perf_counter(); r = fn(*a, **k); acc[name] = acc.get(name, 0.0) + _t.perf_counter() - t; return r
     return w
-port.pack = timed("pack", port.pack); port.rebuild = timed("rebuild", port.rebuild)
+port.pack = timed("pack", port.pack); port.rebuild = timed("rebuild", port.rebuild); port.pack_wait = timed("pack_wait", port.pack_wait)
 comm.exchange = timed("comm", comm.exchange); se.e.step_frame = timed("step_frame(launch)", se.e.step_frame)
 se.exchange = timed("exchange(total)", se.exchange)
 sc.sph.SetComputeParams = timed("SetComputeParams", sc.sph.SetComputeParams)

@@ -68,7 +68,7 @@ struct sph_ctx {
     int* cumBase = nullptr;           // allocation behind the cumulative cell table
     int* cumT = nullptr;              // T[c] = #particles with cell <= c (16-byte aligned, T[-1] = 0)
     int* cellCum = nullptr;           // = T - 1: cellCum[c] = #particles with cell < c; [cells + 1] entries
-    int* cumBlocks = nullptr;         // per-4096-cell block maxima / prefixes
+    int* cumBlocks = nullptr;         // particles per 4096-cell tile of the table (k_cum_block_sum), the seeds of its scan
     uint32_t* keys[2] = {nullptr, nullptr};
     uint32_t* vals[2] = {nullptr, nullptr};
     uint32_t* sid = nullptr;
@@ -120,6 +120,7 @@ struct sph_ctx {
     bool slabMismatchClean = false;   // slab mode: phaseMismatch was read as 0 at the last grid build (covers this frame's records)
     bool skipGhostForce = true;       // SPH_HIP_GHOST_FORCE=1 switches the skip off (A/B)
     bool uniformMassOk = true;        // SPH_HIP_UNIFORM_MASS=0 switches the 12-byte candidate path off (A/B)
+    bool uniformPhaseOk = true;       // SPH_HIP_UNIFORM_PHASE=0: the force kernel always decodes mass / viscosity by phase (A/B)
     int cachedMisses = -1;            // SPH_CTR_BAND_MISSES as read along with the survivor count of a slab build
     bool slabPackedOff = false;       // the phase table changed after the records were uploaded
     SlabRecord* recStage = nullptr;   // device staging for slab upload / download
@@ -412,6 +413,8 @@ int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
     {   // counts -> cumulative cell table
         const long long cells4 = (c->tableCells + 3) / 4;
         const int cb = (int)((c->tableCells + kScanTile - 1) / kScanTile);
+        // (counting the tile sums in k_hash_count instead -- one atomic per wave and 4096-cell tile -- was tried: the fluid
+        // sits in a few dozen tiles, the atomics serialise on their addresses and the grid build went from 74 to 119 us)
         hipLaunchKernelGGL(k_cum_block_sum, dim3(cb), dim3(kBlock), 0, c->stream, (const int4*)c->cumT, cells4,
                            c->cumBlocks);
         hipLaunchKernelGGL(k_cum_write, dim3(cb), dim3(kBlock), 0, c->stream, (int4*)c->cumT, cells4, c->cumBlocks);
@@ -519,7 +522,7 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
                          (const int*)c->cellCum, (const int*)c->counters, mask, c->capacity, nbr, skeys, c->blockInts,
                          (const float*)nullptr, 0.0f);
             if (c->slab)
-                hipLaunchKernelGGL(k_slab_shift_reduce, dim3(1), dim3(kBlock), 0, c->stream, c->blockInts, nb,
+                hipLaunchKernelGGL(k_slab_shift_reduce, dim3((nb + kShiftPerGroup - 1) / kShiftPerGroup), dim3(kBlock), 0, c->stream, c->blockInts, nb,
                                    c->counters + SPH_CTR_MAX_PLANE_SHIFT);
             c->maskValid = c->useHitMask && c->hitMask;
             c->packedValid = packed;
@@ -529,35 +532,45 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
             float4* velOut = c->set[1 - c->velCur].velV;
             // timed sub-step: the span runs from the first launch (band workgroups, or the only one) to the last
             const int f0 = (c->tevSub && wgPhase != 0) ? E_FORCE0 : -1, f1 = (c->tevSub && wgPhase != 1) ? E_FORCE1 : -1;
-            if (c->debug) {
-                const int variant = !c->maskValid ? 0 : (c->packedValid && (c->slab ? !c->slabPackedOff : !c->staticDirty)) ? 2 : 1;
-                if (variant != c->lastForceVariant) {
-                    static const char* const names[3] = {"k_force_xsph_rows (scan)", "k_force_xsph_hits (hit mask, three gathers)",
-                                                         "k_force_xsph_hits (hit mask, packed neighbour records)"};
-                    fprintf(stderr, "[libsph_hip] CS_ForceXSPH -> %s%s\n", names[variant], c->slab ? " [slab]" : "");
-                    c->lastForceVariant = variant;
+            // which kernel: no fresh hit mask -> scan; else the hit path with 0 = three gathers per neighbour, 1 = packed
+            // records + per-phase decode, 2 = packed records, uniform mass and viscosity (see k_force_xsph_hits).  Slab
+            // mode takes a packed mode only when the mismatch flag was read as clean for this frame's records.
+            int mode = -1;
+            if (c->maskValid) {
+                const bool packedOk = c->packedValid && (c->slab ? (!c->slabPackedOff && c->slabMismatchClean) : !c->staticDirty);
+                mode = 0;
+                if (packedOk) {
+                    mode = 2;
+                    for (size_t k = 1; k < c->phaseTable.size(); k++)
+                        if (c->phaseTable[k].mass != c->phaseTable[0].mass || c->phaseTable[k].viscosity != c->phaseTable[0].viscosity)
+                            mode = 1;
+                    if (!c->uniformPhaseOk) mode = 1;
                 }
             }
-            if (c->maskValid && c->packedValid && (c->slab ? !c->slabPackedOff : !c->staticDirty)) {
-                float m[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
-                for (size_t k = 0; k < c->phaseTable.size() && k < 4; k++) {
-                    m[k] = c->phaseTable[k].mass;
-                    v[k] = c->phaseTable[k].viscosity;
-                }
-                const PhaseConsts ph{m[0], m[1], m[2], m[3], v[0], v[1], v[2], v[3]};
-                LAUNCH_T(c, f0, f1, k_force_xsph_hits<true>, dim3(nb), c->dp, (const float4*)s.posM, (const float4*)s.velV,
-                         (const float2*)s.rhoP, s.acc, velOut, (const int*)c->cellCum, (const int*)c->counters,
-                         (const uint32_t*)c->hitMask, c->capacity, (const float4*)c->nbrA, (const float4*)c->nbrB, ph,
-                         c->slab ? (const int*)c->phaseMismatch : (const int*)nullptr, fused ? 1 : 0);
-            } else if (c->maskValid) {
-                LAUNCH_T(c, f0, f1, k_force_xsph_hits<false>, dim3(nb), c->dp, (const float4*)s.posM, (const float4*)s.velV,
-                         (const float2*)s.rhoP, s.acc, velOut, (const int*)c->cellCum, (const int*)c->counters,
-                         (const uint32_t*)c->hitMask, c->capacity, (const float4*)nullptr, (const float4*)nullptr, PhaseConsts{},
-                         (const int*)nullptr, fused ? 1 : 0);
-            } else {
+            if (c->debug && mode != c->lastForceVariant) {
+                static const char* const names[4] = {"k_force_xsph_rows (scan)", "k_force_xsph_hits<0> (hit mask, three gathers)",
+                                                     "k_force_xsph_hits<1> (hit mask, packed neighbour records, per-phase decode)",
+                                                     "k_force_xsph_hits<2> (hit mask, packed neighbour records, uniform mass / viscosity)"};
+                fprintf(stderr, "[libsph_hip] CS_ForceXSPH -> %s%s\n", names[mode + 1], c->slab ? " [slab]" : "");
+                c->lastForceVariant = mode;
+            }
+            float m[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
+            for (size_t k = 0; k < c->phaseTable.size() && k < 4; k++) {
+                m[k] = c->phaseTable[k].mass;
+                v[k] = c->phaseTable[k].viscosity;
+            }
+            const PhaseConsts ph{m[0], m[1], m[2], m[3], v[0], v[1], v[2], v[3]};
+#define FORCE_HITS(MODE_)                                                                                                     \
+    LAUNCH_T(c, f0, f1, k_force_xsph_hits<MODE_>, dim3(nb), c->dp, (const float4*)s.posM, (const float4*)s.velV,             \
+             (const float2*)s.rhoP, s.acc, velOut, (const int*)c->cellCum, (const int*)c->counters, (const uint32_t*)c->hitMask, \
+             c->capacity, (const float4*)c->nbrA, (const float4*)c->nbrB, ph, fused ? 1 : 0)
+            if (mode == 2) FORCE_HITS(2);
+            else if (mode == 1) FORCE_HITS(1);
+            else if (mode == 0) FORCE_HITS(0);
+            else
                 LAUNCH_T(c, f0, f1, k_force_xsph_rows, dim3(nb), c->dp, (const float4*)s.posM, (const float4*)s.velV,
                          (const float2*)s.rhoP, s.acc, velOut, (const int*)c->cellCum, (const int*)c->counters, fused ? 1 : 0);
-            }
+#undef FORCE_HITS
             if (wgPhase != 1) c->velCur = 1 - c->velCur;
             break;
         }
@@ -623,6 +636,7 @@ int sph_create(sph_ctx** out, int device_id) {
     if (const char* xr = getenv("SPH_HIP_XCD_RUN")) c->xcdRunOverride = atoi(xr);
     if (const char* dbg = getenv("SPH_HIP_DEBUG")) c->debug = atoi(dbg) != 0;
     if (const char* um = getenv("SPH_HIP_UNIFORM_MASS")) c->uniformMassOk = atoi(um) != 0;
+    if (const char* up = getenv("SPH_HIP_UNIFORM_PHASE")) c->uniformPhaseOk = atoi(up) != 0;
     if (const char* gf = getenv("SPH_HIP_GHOST_FORCE")) c->skipGhostForce = atoi(gf) == 0;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;

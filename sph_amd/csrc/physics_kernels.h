@@ -1,6 +1,8 @@
 // physics_kernels.h -- per-particle SPH stages on the slot-ordered SoA state (gfx950).
 // Each kernel states the reference kernel it stands in for (Assets/SPHCompute.compute).
 #pragma once
+#include <type_traits>
+
 #include "grid_kernels.h"
 
 namespace sph {
@@ -183,9 +185,11 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
     // phaseMismatch flag, as the force kernel reads it) cost 0.24 instead of 0.13 ms; the host decides instead
     constexpr bool uniform = UNIFORM_MASS;
     RowRange r = range_at(P, cellCum, c, 0, capped, true);
-#pragma unroll 1
-    for (int t = 0; t < nRanges; t++) {
-        const RowRange nxt = range_at(P, cellCum, c, t + 1, capped, t + 1 < nRanges);
+    // One row's walk.  SELF: some lane of the wave has its own slot in this row, so candidates are also tested
+    // against the lane's slot (compute:173); in the other rows (about two of three) those four compares and ANDs per
+    // group are dropped -- a wave-uniform choice per row, same results.
+    auto walk_row = [&](auto selfTag) {
+        constexpr bool SELF = decltype(selfTag)::value;
         const int last = r.e - 1;
         for (int j = r.a; j < r.e; j += 4) {
             // one 32-bit byte offset + immediates: slots past the row's end are loaded (the arrays
@@ -210,10 +214,10 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
             const float t1 = q1.w * P.poly6 * d1 * d1 * d1;
             const float t2 = q2.w * P.poly6 * d2 * d2 * d2;
             const float t3 = q3.w * P.poly6 * d3 * d3 * d3;
-            const bool k0 = rs0 < P.h2 && j != s;
-            const bool k1 = j + 1 <= last && rs1 < P.h2 && j + 1 != s;
-            const bool k2 = j + 2 <= last && rs2 < P.h2 && j + 2 != s;
-            const bool k3 = j + 3 <= last && rs3 < P.h2 && j + 3 != s;
+            const bool k0 = rs0 < P.h2 && (!SELF || j != s);
+            const bool k1 = j + 1 <= last && rs1 < P.h2 && (!SELF || j + 1 != s);
+            const bool k2 = j + 2 <= last && rs2 < P.h2 && (!SELF || j + 2 != s);
+            const bool k3 = j + 3 <= last && rs3 < P.h2 && (!SELF || j + 3 != s);
             // branch-free: a rejected candidate adds +0.0f, which leaves the running sum
             // bit-identical (every term is >= 0), so no exec-mask juggling per candidate
             density += k0 ? t0 : 0.0f;
@@ -233,6 +237,12 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
                 }
             }
         }
+    };
+#pragma unroll 1
+    for (int t = 0; t < nRanges; t++) {
+        const RowRange nxt = range_at(P, cellCum, c, t + 1, capped, t + 1 < nRanges);
+        if (__any(s >= r.a && s < r.e)) walk_row(std::true_type{});
+        else walk_row(std::false_type{});
         if (recording && sh != 0) {                      // rows are padded to whole words
             if (wi < kMaskStage) maskStage[wi][threadIdx.x] = word;
             else if (wi < kMaskWords) mrowHi[wi] = word;
@@ -280,16 +290,22 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
 }
 
 // slab mode: maximum of the per-workgroup plane shifts left by the density kernel
+constexpr int kShiftPerGroup = 2048;
 __global__ __launch_bounds__(kBlock) void k_slab_shift_reduce(const int* __restrict__ blockShift, int nBlocks,
                                                               int* __restrict__ counter) {
     __shared__ int ws[kBlock / 64];
     int m = 0;
-    for (int b = threadIdx.x; b < nBlocks; b += kBlock) m = max(m, blockShift[b]);
+    // every workgroup folds kShiftPerGroup entries (one workgroup over 32 k entries took 25 us at 8.4 M particles)
+    const int b0 = blockIdx.x * kShiftPerGroup, b1 = min(b0 + kShiftPerGroup, nBlocks);
+    for (int b = b0 + (int)threadIdx.x; b < b1; b += kBlock) m = max(m, blockShift[b]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(counter, max(max(ws[0], ws[1]), max(ws[2], ws[3])));
+    if (threadIdx.x == 0) {
+        const int tot = max(max(ws[0], ws[1]), max(ws[2], ws[3]));
+        if (tot > 0) atomicMax(counter, tot);
+    }
 }
 
 // One in-range pair of CS_ForceXSPH (compute:250-277) with explicit FMAs and hardware
@@ -299,6 +315,7 @@ struct ForceAcc {
     float fx, fy, fz, cgx, cgy, cgz, cl, vcx, vcy, vcz, norm;
 };
 
+template <bool UNI = false>
 __device__ __forceinline__ void force_pair(const DevParams& P, ForceAcc& A, const float4 p, const float4 v,
                                            float densitySelf, float selfTerm, const float4 q, const float4 u,
                                            const float2 o) {
@@ -318,7 +335,9 @@ __device__ __forceinline__ void force_pair(const DevParams& P, ForceAcc& A, cons
     const float pf = -q.w * pressureTerm;
     const float dvx = u.x - v.x, dvy = u.y - v.y, dvz = u.z - v.z;        // compute:261
     const float mor = q.w * invRho;                                       // m_j / rho_j
-    const float vm = ((0.5f * (v.w + u.w)) * mor) * (P.viscLapFactor * (P.h - dist));   // compute:263-265
+    // UNI: every phase has the same viscosity, v.w == u.w and 0.5 (a + a) == a exactly
+    const float viscMean = UNI ? u.w : 0.5f * (v.w + u.w);
+    const float vm = (viscMean * mor) * (P.viscLapFactor * (P.h - dist));               // compute:263-265
     A.fx = fmaf(pf, gwx, fmaf(vm, dvx, A.fx));                            // compute:258, 265
     A.fy = fmaf(pf, gwy, fmaf(vm, dvy, A.fy));
     A.fz = fmaf(pf, gwz, fmaf(vm, dvz, A.fz));
@@ -483,7 +502,12 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_rows(DevParams P, const f
 // k_density_pressure_rows on exactly these positions and this grid.  A wave falls back to the scan
 // path if a bin overflowed (27 capped ranges, no mask) or any of its particles needs more mask words
 // than a row holds.
-template <bool PACKED>
+// MODE 0: a neighbour is three gathers (posM, velV, rhoP).  MODE 1: two packed records (PackedNbr), mass / viscosity
+// looked up by the phase id in their sign bits.  MODE 2: packed records and EVERY phase has the same particle mass and
+// the same viscosity (ph.m0, ph.v0: true of all the BASELINE configurations, whose phases differ in rest density only),
+// so there is nothing to decode.  The host picks the mode (libsph_hip.hip); in slab mode it takes a packed mode only
+// after it has read the record / phase-table mismatch flag as clean for this frame's records.
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const float4* __restrict__ posM,
                                                             const float4* __restrict__ velIn,
                                                             const float2* __restrict__ rhoP,
@@ -493,7 +517,7 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
                                                             const uint32_t* __restrict__ hitMask, int maskStride,
                                                             const float4* __restrict__ nbrA,
                                                             const float4* __restrict__ nbrB, PhaseConsts ph,
-                                                            const int* __restrict__ phaseMismatch, int zeroDeadAcc) {
+                                                            int zeroDeadAcc) {
     // one buffer, two uses: (a) per lane the non-empty mask words and the slot of their bit 0,
     // (b) the scan path's hit FIFO.  Every thread only touches its own column.
     static_assert(kMaskWords + 9 >= kHitQueue, "the FIFO lives in the word list's LDS");
@@ -575,8 +599,7 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
                 }
             }
         }
-        // (slab mode: a record whose mass / viscosity is not its phase's row switches the packed path off)
-        const bool packed = PACKED && (!phaseMismatch || *phaseMismatch == 0);
+        constexpr bool packed = MODE != 0;
         // 3) walk the set bits: visiting order, one add per hit to find its slot
         int li = 0, base = 0;
         uint32_t w = 0;
@@ -615,6 +638,7 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
         auto unpack = [&](float4& q, float4& u, float2& o) {
             const bool b0 = (__float_as_uint(q.w) >> 31) != 0, b1 = (__float_as_uint(u.w) >> 31) != 0;
             o = make_float2(fabsf(q.w), fabsf(u.w));
+            if (MODE == 2) { q.w = ph.m0; u.w = ph.v0; return; }
             const float mLo = b0 ? ph.m1 : ph.m0, mHi = b0 ? ph.m3 : ph.m2;
             const float vLo = b0 ? ph.v1 : ph.v0, vHi = b0 ? ph.v3 : ph.v2;
             q.w = b1 ? mHi : mLo;
@@ -622,8 +646,8 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
         };
         auto compute = [&](Stage& S) {
             if (packed) { unpack(S.q0, S.u0, S.o0); unpack(S.q1, S.u1, S.o1); }
-            if (S.h0) force_pair(P, A, me.p, me.v, me.densitySelf, me.selfTerm, S.q0, S.u0, S.o0);
-            if (S.h1) force_pair(P, A, me.p, me.v, me.densitySelf, me.selfTerm, S.q1, S.u1, S.o1);
+            if (S.h0) force_pair<MODE == 2>(P, A, me.p, me.v, me.densitySelf, me.selfTerm, S.q0, S.u0, S.o0);
+            if (S.h1) force_pair<MODE == 2>(P, A, me.p, me.v, me.densitySelf, me.selfTerm, S.q1, S.u1, S.o1);
         };
         Stage SA, SB;
         fetch(SA);
