@@ -160,8 +160,10 @@ class NeighbourComm:
         self.backend = backend or dist.get_backend()
         self.stage_cpu = self.backend == "gloo"
         dev = self._dev()
-        self.cnt_send = torch.zeros(2, dtype=torch.int64, device=dev)
-        self.cnt_recv = torch.zeros(2, dtype=torch.int64, device=dev)
+        # per face: [record count, ghost width the sender needs (adaptive ghost width; 0 = not in use)]
+        self.cnt_send = torch.zeros((2, 2), dtype=torch.int64, device=dev)
+        self.cnt_recv = torch.zeros((2, 2), dtype=torch.int64, device=dev)
+        self.peer_need = (0, 0)          # what the left / right neighbour said it needs, as of the last exchange
         self.cap = int(msg_capacity)
         self.buf = [torch.empty((self.cap, REC), dtype=torch.uint8, device=dev) for _ in range(2)] if self.cap else None
 
@@ -183,24 +185,27 @@ class NeighbourComm:
             return self.buf[side][:n]
         return self.torch.empty((n, REC), dtype=self.torch.uint8, device=self._dev())
 
-    def exchange(self, to_left, to_right):
-        """Send to_left to rank-1 and to_right to rank+1; returns (from_left, from_right)."""
+    def exchange(self, to_left, to_right, need=0):
+        """Send to_left to rank-1 and to_right to rank+1; returns (from_left, from_right).  `need` (an int) rides in
+        the count message to both neighbours; theirs end up in self.peer_need."""
         torch = self.torch
         left = self.rank - 1 if self.rank > 0 else None
         right = self.rank + 1 if self.rank < self.world - 1 else None
         if left is None and right is None:
             return None, None
         # 1) counts (two preallocated int64 pairs; fill_ is asynchronous, tolist() is the one sync)
-        self.cnt_send[0:1].fill_(int(to_left.shape[0]))
-        self.cnt_send[1:2].fill_(int(to_right.shape[0]))
+        self.cnt_send[0, 0:1].fill_(int(to_left.shape[0]))
+        self.cnt_send[1, 0:1].fill_(int(to_right.shape[0]))
+        self.cnt_send[:, 1:2].fill_(int(need))
         self.cnt_recv.zero_()
         sends, recvs = [], []
         if left is not None:
-            sends.append((self.cnt_send[0:1], left)); recvs.append((self.cnt_recv[0:1], left))
+            sends.append((self.cnt_send[0], left)); recvs.append((self.cnt_recv[0], left))
         if right is not None:
-            sends.append((self.cnt_send[1:2], right)); recvs.append((self.cnt_recv[1:2], right))
+            sends.append((self.cnt_send[1], right)); recvs.append((self.cnt_recv[1], right))
         self._xfer(sends, recvs)
-        n_from_l, n_from_r = (int(v) for v in self.cnt_recv.tolist())
+        (n_from_l, need_l), (n_from_r, need_r) = ((int(v) for v in row) for row in self.cnt_recv.tolist())
+        self.peer_need = (need_l, need_r)
         # 2) payload
         dev = self._dev()
         buf_l, buf_r = self._recv_buffer(0, n_from_l), self._recv_buffer(1, n_from_r)
@@ -281,9 +286,23 @@ class SlabEngine:
 
     def __init__(self, port, comm: NeighbourComm, rank: int, world: int, ghost_planes: int = 8,
                  capacity_factor: float = 1.6, rebalance_every: int = 0, max_cut_shift: Optional[int] = None,
-                 rebalance_threshold: float = 1.05, overlap: bool = False):
+                 rebalance_threshold: float = 1.05, overlap: bool = False, adaptive_ghost: bool = False,
+                 min_ghost: int = 4, shift_window: int = 8):
         self.port, self.comm, self.rank, self.world = port, comm, rank, world
-        self.ghost = int(ghost_planes)
+        self.ghost = int(ghost_planes)                        # the widest the ghost region ever gets (capacity, slab widths)
+        # Adaptive ghost width: the halo condition is ghost >= 2 subSteps (1 + max plane shift), and the shift is what
+        # the blow-up of the first frames makes it (5 planes at the spawn density of configs 4 / 5, 2 afterwards).  Each
+        # FACE keeps its own width: both of its ranks tell each other, in the count message of the frame's exchange,
+        # the width they need (from the shifts their density kernels measured over the last `shift_window` frames, + 2
+        # planes of margin); the face takes the larger.  Narrower first on the keep side (what is in flight was packed
+        # wider), wider first on the send side.  No collective, no extra message.
+        self.adaptive = bool(adaptive_ghost)
+        self.min_ghost = int(min_ghost)
+        self.wk = [self.ghost, self.ghost]                    # planes of the left / right neighbour's territory kept as ghosts
+        self.ws = [self.ghost, self.ghost]                    # planes of OWN territory sent to the left / right neighbour
+        self._shifts = []
+        self._shift_window = int(shift_window)
+        self.width_changes = 0
         self.capacity_factor = capacity_factor
         self.rebalance_every = int(rebalance_every)           # 0: static, equal plane counts
         self.max_cut_shift = self.ghost if max_cut_shift is None else int(max_cut_shift)
@@ -296,7 +315,8 @@ class SlabEngine:
         self.overlap = bool(overlap)
         if self.overlap and self.rebalance_every:
             raise ValueError("overlap and moving cuts are not combined yet")
-        self.band_margin = max(self.ghost // 2, 1)     # planes a particle may move per frame under the halo condition
+        if self.adaptive and self.rebalance_every:
+            raise ValueError("adaptive ghost width and moving cuts are not combined yet")
         self.band_misses = 0
         self.band_fraction = 0.0       # share of the last force kernel that ran before the pack
         self._primed = False
@@ -313,6 +333,7 @@ class SlabEngine:
         self.sub_steps = 1            # of the last frame (sets the halo width the frame needed)
         self.frames = 0
         self.exchange_s = 0.0
+        self.n_built = 0
 
     # ---- particle creation: the host feeds spawned rows chunk by chunk (host.SPH.CreateParticles)
     grid_first = True
@@ -378,7 +399,57 @@ class SlabEngine:
             raise ValueError(f"moving cuts need slabs of at least 2 x {self.ghost} ghost planes + {self.max_cut_shift} "
                              f"planes of cut shift; the narrowest has {narrowest}")
         self.own = (x0, x1)
-        self.keep = (max(x0 - self.ghost, 0), min(x1 + self.ghost, rx))
+        self.wk = [self.ghost, self.ghost]
+        self.ws = [self.ghost, self.ghost]
+        self._shifts = []
+        self.keep = self._keep_range()
+
+    def _keep_range(self):
+        return (max(self.own[0] - self.wk[0], 0), min(self.own[1] + self.wk[1], self.grid[0]))
+
+    @property
+    def band_margin(self):
+        """Planes a particle may move per frame while the halo condition holds (half the ghost width)."""
+        return max(min(self.ws) // 2, 1)
+
+    # ---- adaptive ghost width
+    def _needed(self):
+        """Ghost width this rank asks of its faces: 2 subSteps (1 + largest shift of the last frames) + 2 planes of margin
+        (a width takes a frame or two to grow); the full width until a window of frames has been seen."""
+        if not self.adaptive or len(self._shifts) < self._shift_window:
+            return self.ghost
+        need = 2 * self.sub_steps * (1 + max(self._shifts[-self._shift_window:])) + 2
+        return int(min(max(need, self.min_ghost), self.ghost))
+
+    def _note_shift(self, shift, widths=None):
+        """`shift`: the largest plane shift the density kernel measured in the frame that ran with ghost widths `widths`."""
+        widths = self.wk if widths is None else widths
+        self._shifts.append(int(shift))
+        del self._shifts[:-self._shift_window]
+        faces = [widths[k] for k in (0, 1) if (self.rank > 0 if k == 0 else self.rank < self.world - 1)]
+        if faces and 2 * self.sub_steps * (1 + shift) > min(faces):
+            self.halo_violations += 1
+
+    def _adapt(self, in_flight: bool):
+        """New face widths from this rank's need and the neighbours' (comm.peer_need, same frame): both ranks of a face
+        compute the same numbers.  in_flight: the records about to be appended were packed with the OLD send widths, so a
+        face can only be kept as wide as that (growing takes effect on the send side first)."""
+        if not self.adaptive or self.world == 1:
+            return
+        own = self._needed()
+        changed = False
+        for k in (0, 1):
+            if (k == 0 and self.rank == 0) or (k == 1 and self.rank == self.world - 1):
+                continue
+            target = int(min(max(own, self.comm.peer_need[k], self.min_ghost), self.ghost))
+            keep = min(target, self.ws[k]) if in_flight else target
+            changed |= keep != self.wk[k]
+            self.wk[k], self.ws[k] = keep, target
+        if changed:
+            rx, ry, rz, cap = self.grid
+            self.keep = self._keep_range()
+            self.port.reconfigure(rx, self.keep[0], self.keep[1] - self.keep[0], ry, rz, cap, self.own[0], self.own[1])
+            self.width_changes += 1
 
     @property
     def min_width(self):
@@ -404,7 +475,7 @@ class SlabEngine:
         self.cuts = cuts
         x0, x1 = cuts[self.rank], cuts[self.rank + 1]
         self.own = (x0, x1)
-        self.keep = (max(x0 - self.ghost, 0), min(x1 + self.ghost, rx))
+        self.keep = self._keep_range()
         self.port.reconfigure(rx, self.keep[0], self.keep[1] - self.keep[0], ry, rz, cap, x0, x1)
         self.recuts += 1
         return True
@@ -485,16 +556,15 @@ class SlabEngine:
         t0 = time.perf_counter()
         if self.rebalance_every and self.world > 1 and self.frames > 0 and self.frames % self.rebalance_every == 0:
             self.rebalance()
-        x0, x1 = self.own
-        rx = self.grid[0]
-        left_below = x0 + self.ghost if self.rank > 0 else 0
-        right_from = x1 - self.ghost if self.rank < self.world - 1 else rx
+        # classic order: nothing is in flight, so the widths agreed on from LAST frame's needs apply to this frame's
+        # pack, keep range and grid at once
+        ran_with = list(self.wk)
+        self._adapt(in_flight=False)
+        left_below, right_from = self._send_range()
         to_l, to_r = self.port.pack(left_below, right_from)
         if self.frames > 0 and self.world > 1:
-            shift = self.e.read_counter(abi.CTR_MAX_PLANE_SHIFT)     # came back with pack's counts: no extra sync
-            if 2 * self.sub_steps * (1 + shift) > self.ghost:
-                self.halo_violations += 1
-        from_l, from_r = self.comm.exchange(to_l, to_r)
+            self._note_shift(self.e.read_counter(abi.CTR_MAX_PLANE_SHIFT), ran_with)   # came back with pack's counts: no extra sync
+        from_l, from_r = self.comm.exchange(to_l, to_r, need=self._needed())
         self.n = self.port.rebuild(self.keep[0], self.keep[1], from_l, from_r)
         self.e.n = self.n
         self.exchange_s += time.perf_counter() - t0
@@ -505,11 +575,12 @@ class SlabEngine:
         if hasattr(self.port, "local_count"):
             self.n = self.port.local_count()
             self.e.n = self.n
+        self.n_built = self.n          # owned + ghosts as of the last grid build
 
     def _send_range(self):
         x0, x1 = self.own
-        return (x0 + self.ghost if self.rank > 0 else 0,
-                x1 - self.ghost if self.rank < self.world - 1 else self.grid[0])
+        return (x0 + self.ws[0] if self.rank > 0 else 0,
+                x1 - self.ws[1] if self.rank < self.world - 1 else self.grid[0])
 
     def step_frame(self, sub_steps, time_step):
         self.sub_steps = int(sub_steps)
@@ -532,10 +603,9 @@ class SlabEngine:
         t0 = time.perf_counter()
         to_l, to_r = self.port.pack_wait()          # the band part of the frame is done; the GPU carries on
         self.band_fraction = getattr(self.e, "band_workgroups", 0) / max((self.n + 255) // 256, 1)
-        shift = self.e.read_counter(abi.CTR_MAX_PLANE_SHIFT)
-        if 2 * self.sub_steps * (1 + shift) > self.ghost:
-            self.halo_violations += 1
-        from_l, from_r = self.comm.exchange(to_l, to_r)
+        self._note_shift(self.e.read_counter(abi.CTR_MAX_PLANE_SHIFT))
+        from_l, from_r = self.comm.exchange(to_l, to_r, need=self._needed())
+        self._adapt(in_flight=True)              # the records just received were packed with the widths of this frame
         self.n = self.port.rebuild(self.keep[0], self.keep[1], from_l, from_r)   # enqueued behind the frame
         self.e.n = self.n
         self.exchange_s += time.perf_counter() - t0
@@ -631,7 +701,10 @@ def bench_main(args, rank, local_rank, world):
     # 12 ghost planes: at the spawn density of configs 4/5 (7 x rest density) the first frames throw particles up to
     # 5 cell planes per frame (scripts/max_shift.py), and the halo condition is ghost >= 2 (1 + shift); 2-3 planes later
     ghost = int(os.environ.get("SPH_BENCH_GHOST", "12"))
-    se = SlabEngine(port, comm, rank, world, ghost_planes=ghost, rebalance_every=rebalance, overlap=overlap)
+    # SPH_BENCH_ADAPTIVE_GHOST=0: keep the full ghost width for the whole run (A/B)
+    adaptive = os.environ.get("SPH_BENCH_ADAPTIVE_GHOST", "1") != "0" and not rebalance
+    se = SlabEngine(port, comm, rank, world, ghost_planes=ghost, rebalance_every=rebalance, overlap=overlap,
+                    adaptive_ghost=adaptive)
     sc = scenes.config4(se, n=n_all) if strong else scenes.config5(se, gpus=world, per_gpu=per_gpu)
     sc.sph.use_step_frame = True
     sc.start()
@@ -661,6 +734,11 @@ def bench_main(args, rank, local_rank, world):
     misses = comm.allreduce_sum(se.band_misses)
     overflow = comm.allreduce_sum(eng.read_counter(abi.CTR_BIN_OVERFLOW))
     force_ms = comm.allreduce_max(tm["force_ms"])
+    n_owned_here = int(se.owned_records().shape[0]) if os.environ.get("SPH_BENCH_GHOST_RATIO", "1") != "0" else -1
+    ghost_ratio = comm.allreduce_max((se.n_built - n_owned_here) / max(n_owned_here, 1)) if n_owned_here >= 0 else None
+    faces = [se.wk[k] for k in (0, 1) if (rank > 0 if k == 0 else rank < world - 1)] or [ghost]
+    widths_min = -comm.allreduce_max(-float(min(faces)))
+    widths_max = comm.allreduce_max(float(max(faces)))
     # The same per-GPU load on ONE GPU, no slabs (every rank runs it on its own GPU, concurrently): what
     # "weak scaling" compares with.  bench.py --gpus 1 runs config 3 (1 M particles), a different workload.
     solo = None
@@ -713,6 +791,8 @@ def bench_main(args, rank, local_rank, world):
                        "world_size": dist.get_world_size(), "backend": dist.get_backend(), "rehearsal": rehearsal,
                        "self_launched": os.environ.get("SPH_BENCH_SELF_LAUNCHED") == "1",
                        "halo_violations": viol, "bin_overflow_cells": overflow,
+                       "adaptive_ghost": se.adaptive, "ghost_planes_at_end": [int(widths_min), int(widths_max)],
+                       "ghost_to_owned_particles_worst_rank": ghost_ratio,
                        "rebalance_every": se.rebalance_every, "recuts": se.recuts,
                        "exchange_overlapped": se.overlap, "band_fraction_rank0": round(se.band_fraction, 4),
                        "band_misses": misses,

@@ -138,7 +138,12 @@ class OraclePort:
         cop = self.ora.download_grid()[3].astype(np.int64)
         self._bin_plane = cop % self.rx
         self.owned_mask = (self._bin_plane >= self.own[0]) & (self._bin_plane < self.own[1])
-        self.max_shift = 0                          # not measured on this port
+        # what the engine's density kernel measures (SPH_CTR_MAX_PLANE_SHIFT), from the frame's final positions:
+        # planes moved against the binned plane, owned particles
+        aos = self.ora.download_particles()
+        now = self._planes(aos[:, 0], self.params)
+        own = self.owned_mask & (self.ids != 0xFFFFFFFF)
+        self.max_shift = int(np.abs(now[own] - self._bin_plane[own]).max(initial=0))
 
     def download_owned(self):
         recs, owned, _ = self._current()

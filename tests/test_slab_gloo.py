@@ -62,7 +62,7 @@ def _free_port():
 
 
 def _worker(rank, world, port, frames, out_dir, step_frame, ghost=8, rebalance_every=0, sub_steps=1, overlap=False,
-            motion=None):
+            motion=None, adaptive=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -71,7 +71,7 @@ def _worker(rank, world, port, frames, out_dir, step_frame, ghost=8, rebalance_e
     oport = OraclePort(Oracle())
     comm = slab.NeighbourComm(rank, world, torch.device("cpu"), backend="gloo")
     se = slab.SlabEngine(oport, comm, rank, world, ghost_planes=ghost, rebalance_every=rebalance_every,
-                         max_cut_shift=4, rebalance_threshold=1.0, overlap=overlap)
+                         max_cut_shift=4, rebalance_threshold=1.0, overlap=overlap, adaptive_ghost=adaptive, shift_window=3)
     orig = se.set_params
 
     def set_params(p):
@@ -90,6 +90,7 @@ def _worker(rank, world, port, frames, out_dir, step_frame, ghost=8, rebalance_e
     np.save(os.path.join(out_dir, f"counts{rank}.npy"), np.array(counts))
     np.save(os.path.join(out_dir, f"cuts{rank}.npy"), np.array(se.cuts + [se.recuts]))
     np.save(os.path.join(out_dir, f"repart{rank}.npy"), np.array([getattr(se, "repartitions", 0)]))
+    np.save(os.path.join(out_dir, f"widths{rank}.npy"), np.array(se.wk + se.ws + [se.width_changes, se.halo_violations]))
     dist.destroy_process_group()
 
 
@@ -152,6 +153,34 @@ def test_overlapped_driver_equals_single_domain(tmp_path, oracle_built):
     got = abi.aos_from_records(recs[np.argsort(recs["id"])])
     for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
         assert np.array_equal(got[:, sl], want[:, sl]), "overlapped slab run differs from the single-domain run"
+
+
+@pytest.mark.parametrize("world,overlap,step_frame", [(2, False, True), (2, False, False), (3, True, True)])
+def test_adaptive_ghost_width_equals_single_domain(tmp_path, oracle_built, world, overlap, step_frame):
+    """Per-face ghost widths that follow the measured plane shifts (need rides in the count message, no collective):
+    the faces start 8 planes wide, narrow to what 2 (1 + shift) + 2 asks for after a window of frames, both ranks of a
+    face agree, and the result is still the single-domain run bit for bit."""
+    frames = 10
+    from oracle.ora import Oracle
+    ref = Oracle()
+    sc = small_tank(ref)
+    sc.run(frames)
+    want = ref.download_particles()
+    n = want.shape[0]
+    mp.spawn(_worker, args=(world, _free_port(), frames, str(tmp_path), step_frame, 8, 0, 1, overlap, None, True),
+             nprocs=world, join=True)
+    recs = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)])
+    assert np.load(tmp_path / "counts0.npy").tolist() == [n] * frames
+    assert np.array_equal(np.sort(recs["id"]), np.arange(n, dtype=np.uint32))
+    got = abi.aos_from_records(recs[np.argsort(recs["id"])])
+    for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
+        assert np.array_equal(got[:, sl], want[:, sl]), "adaptive ghost width: slab run differs from the single-domain run"
+    w = [np.load(tmp_path / f"widths{r}.npy").tolist() for r in range(world)]       # wkL wkR wsL wsR changes violations
+    assert all(x[5] == 0 for x in w), f"halo violations {w}"
+    assert sum(x[4] for x in w) >= world, f"the widths never changed: {w}"
+    for r in range(world - 1):                                                       # the two ranks of a face agree
+        assert w[r][1] == w[r + 1][0] and w[r][3] == w[r + 1][2], f"face {r}|{r + 1}: {w[r]} vs {w[r + 1]}"
+        assert 4 <= w[r][1] < 8, f"face {r}|{r + 1} did not narrow: {w[r]}"
 
 
 @pytest.mark.parametrize("motion", ["drift", "rock"])

@@ -31,7 +31,7 @@ def long_tank(engine, n=0, sub_steps=1):
 
 
 def _worker(rank, world, port, frames, out_dir, n, ghost, drop_phases, rebalance_every=0, sub_steps=1, overlap=False,
-            tank="small"):
+            tank="small", adaptive=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -39,7 +39,7 @@ def _worker(rank, world, port, frames, out_dir, n, ghost, drop_phases, rebalance
     dport = slab.DevicePort(eng, 0, msg_capacity=n)
     comm = slab.NeighbourComm(rank, world, torch.device("cuda", 0), backend="gloo")
     se = slab.SlabEngine(dport, comm, rank, world, ghost_planes=ghost, rebalance_every=rebalance_every,
-                         max_cut_shift=4, rebalance_threshold=1.0, overlap=overlap)
+                         max_cut_shift=4, rebalance_threshold=1.0, overlap=overlap, adaptive_ghost=adaptive)
     if drop_phases:
         # records arrive without their spawn-box index: the second box's mass / viscosity / rest density
         # then disagree with row 0 of the phase table, and the engine has to notice (PhaseCheck) and
@@ -60,6 +60,8 @@ def _worker(rank, world, port, frames, out_dir, n, ghost, drop_phases, rebalance
     np.save(os.path.join(out_dir, f"meta{rank}.npy"), np.array(counts + [se.halo_violations + se.band_misses]))
     np.save(os.path.join(out_dir, f"cuts{rank}.npy"), np.array(se.cuts + [se.recuts]))
     np.save(os.path.join(out_dir, f"band{rank}.npy"), np.array([se.band_fraction]))
+    owned = se.owned_records().shape[0]
+    np.save(os.path.join(out_dir, f"widths{rank}.npy"), np.array(se.wk + se.ws + [se.width_changes, se.n_built, owned]))
     eng.destroy()
     dist.destroy_process_group()
 
@@ -225,6 +227,34 @@ def test_long_run_overlapped_slabs_bitwise(tmp_path):
     got = abi.aos_from_records(recs[np.argsort(recs["id"])])
     for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
         assert np.array_equal(got[:, sl], want[:, sl]), "120 frames: 4 overlapped slabs differ from one engine"
+
+
+@pytest.mark.parametrize("world,overlap", [(2, False), (4, True)])
+def test_adaptive_ghost_width_bitwise(tmp_path, world, overlap):
+    """Ghost widths that follow the measured plane shifts (per face, agreed through the count message): 12 planes
+    through the blow-up of the first frames, then what 2 (1 + shift) + 2 asks for.  Same bits as one engine, no halo
+    violation, no particle missed by the band, and clearly fewer ghost particles at the end than with the full width."""
+    frames = 40
+    eng = abi.Engine(0)
+    sc = long_tank(eng)
+    sc.sph.use_step_frame = True
+    sc.run(frames)
+    want = eng.download_particles()
+    eng.destroy()
+    n = want.shape[0]
+    mp.spawn(_worker, args=(world, _free_port(), frames, str(tmp_path), n, 12, False, 0, 1, overlap, "long", True), nprocs=world,
+             join=True)
+    recs = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)])
+    meta = np.load(tmp_path / "meta0.npy")
+    assert meta[:-1].tolist() == [n] * frames and meta[-1] == 0, meta[-8:]
+    got = abi.aos_from_records(recs[np.argsort(recs["id"])])
+    for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
+        assert np.array_equal(got[:, sl], want[:, sl]), "adaptive ghost width: slabs differ from one engine"
+    w = [np.load(tmp_path / f"widths{r}.npy").tolist() for r in range(world)]     # wkL wkR wsL wsR changes n_built owned
+    for r in range(world - 1):
+        assert w[r][1] == w[r + 1][0] and w[r][3] == w[r + 1][2], f"face {r}|{r + 1}: the ranks disagree: {w}"
+        assert w[r][1] < 12, f"face {r}|{r + 1} never narrowed: {w}"
+    print("ghost / owned particles per rank:", [round((x[5] - x[6]) / max(x[6], 1), 3) for x in w], "widths", [x[:2] for x in w])
 
 
 def test_plane_counts_equal_download():
