@@ -127,8 +127,9 @@ typedef struct sph_ctx sph_ctx;
  * build_grid_ms runs from the first launch of the grid build to the end of the reorder (which also does the first half
  * step); full_step_ms is the fused tail (full step + boundary + damping); frame_ms from the first launch to the last;
  * half_step_ms / bound_obs_ms / damping_ms are 0 (those stages are fused).  With subSteps > 1 the sub-step stages are
- * those of the last sub-step.  SPH_HIP_TIMING=0 records nothing; SPH_HIP_TIMING_STRIDE=k times every k-th frame
- * (default 1).  `frames` is the number of frames that were timed. */
+ * those of the last sub-step.  SPH_HIP_TIMING=0 records nothing, 2 times every frame; SPH_HIP_TIMING_STRIDE=k times
+ * every k-th frame (default 2: a launch that carries events costs ~70 us of host time, and with five of them in EVERY
+ * frame a 0.4 ms frame loop becomes host-bound).  `frames` is the number of frames that were timed. */
 typedef struct sph_timings {
     float build_grid_ms;   /* hash + counting sort by cell + reorder             */
     float half_step_ms;

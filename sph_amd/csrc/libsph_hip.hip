@@ -144,7 +144,11 @@ struct sph_ctx {
     int ringNext = 0;
     double stageSum[kNumEvents] = {};   // ms; [7] = whole frame
     int timingLevel = 1;                // 0 none, 1 every timingStride-th frame (default), 2 every frame
-    int timingStride = 1;               // level 1: every this-many-th frame is timed (SPH_HIP_TIMING_STRIDE)
+    // level 1: every this-many-th frame is timed (SPH_HIP_TIMING_STRIDE).  A launch that carries events costs ~70 us of
+    // HOST time (hipExtLaunchKernel; five per timed frame), an ordinary one ~3 us: at 1 M particles (0.33-0.44 ms of
+    // GPU time per frame) timing EVERY frame makes the frame loop host-bound (-4 % throughput, scripts/host_rate.py),
+    // every second frame does not -- the host catches up on the untimed frames.
+    int timingStride = 2;
     unsigned eventFlags = hipEventDisableSystemFence;   // SPH_HIP_EVENT_FENCE=1: default events (A/B)
     int framesSinceHarvest = 0;         // level 1 records events on every kTimingStride-th frame only
     int framesTimed = 0;
