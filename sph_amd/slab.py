@@ -675,11 +675,15 @@ def bench_main(args, rank, local_rank, world):
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if not dist.is_initialized():
+        # a collective or send/recv that never completes must end the run (the parent then reports the failure) rather
+        # than hold the node until somebody else's limit
+        import datetime
+        limit = datetime.timedelta(seconds=int(os.environ.get("SPH_BENCH_COMM_TIMEOUT_S", "300")))
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, timeout=limit,
                                     device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=limit)
     # default: BASELINE config 5 (weak scaling, 8,388,608 particles per GPU); --workload config4: BASELINE config 4
     # (strong scaling, 16,777,216 particles in all, --particles overrides the TOTAL)
     strong = getattr(args, "workload", "") == "config4"
