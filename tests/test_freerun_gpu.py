@@ -52,3 +52,37 @@ def test_config1_1000_frames_bounded_drift():
     assert a["com"][1] < 3.0 and b["com"][1] < 3.0
     print({f: {k: (np.round(x[k], 4), np.round(y[k], 4)) for k in ("ke", "pe", "vmax", "rho_mean", "ymax")}
            for f, (x, y) in checkpoints.items()})
+
+
+def test_scene4_two_phase_obb_obstacle_600_frames_bounded_drift_per_phase():
+    """The same regime for the reference's Scene 4 (two phases, OBB boundary cube, orbiting sphere obstacle) at 5 % of its
+    particle count: engine and oracle run 600 frames from the same spawn state without re-synchronisation; aggregates are
+    compared PER PHASE.  Bounds are ~3 x the deviations observed on MI355X (scripts/freerun_probe.py): identical to 1e-4
+    at frame 10, 1e-3-ish at frame 100, chaotic decorrelation afterwards (the tank is 20 x 30 x 20 units)."""
+    from oracle.ora import Oracle
+    eng, ora = abi.Engine(0), Oracle(omp=True)
+    builder = lambda e: scenes.unity_scene(e, which=4, scale_count=0.05)      # noqa: E731
+    se, so = builder(eng), builder(ora)
+    se.sph.use_step_frame = True
+    se.start(); so.start()
+    box = 20.0
+    bounds = {10: dict(com=1e-5, ke=1e-4, pe=1e-4, rho=1e-4), 100: dict(com=1e-3, ke=0.01, pe=0.01, rho=0.01),
+              300: dict(com=0.02, ke=0.25, pe=0.03, rho=0.03), 600: dict(com=0.03, ke=0.30, pe=0.03, rho=0.03)}
+    pe0 = {}
+    for f in range(1, 601):
+        se.frame(); so.frame()
+        if f not in bounds:
+            continue
+        P, Q = eng.download_particles(), ora.download_particles()
+        assert np.isfinite(P).all() and eng.read_counter(abi.CTR_NAN) == 0
+        assert np.array_equal(P[:, 11:14], Q[:, 11:14])                      # static fields never drift
+        for rho0 in (20.0, 10.0):
+            a, b = aggregates(P[P[:, 11] == rho0]), aggregates(Q[Q[:, 11] == rho0])
+            pe0.setdefault(rho0, abs(b["pe"]))                               # potential energy scale: the spawn height
+            t = bounds[f]
+            what = (f, rho0)
+            assert np.abs(a["com"] - b["com"]).max() <= t["com"] * box, (what, a["com"], b["com"])
+            assert abs(a["ke"] - b["ke"]) <= t["ke"] * b["ke"], (what, a["ke"], b["ke"])
+            assert abs(a["pe"] - b["pe"]) <= t["pe"] * pe0[rho0], (what, a["pe"], b["pe"])
+            assert abs(a["rho_mean"] - b["rho_mean"]) <= t["rho"] * b["rho_mean"], (what, a["rho_mean"], b["rho_mean"])
+    eng.destroy()
