@@ -80,9 +80,19 @@ class Transform:
     def lossyScale(self):
         return self.localScale
 
+    def _state_key(self):
+        return self.position.tobytes() + self.rotation.tobytes() + self.localScale.tobytes()
+
     @property
     def localToWorldMatrix(self) -> np.ndarray:
-        """Matrix4x4.TRS(position, rotation, scale), fp32, row-major m[r, c] acting on columns."""
+        """Matrix4x4.TRS(position, rotation, scale), fp32, row-major m[r, c] acting on columns.  Recomputed only when
+        position / rotation / scale changed (the host asks for it ~10 times a frame: 8 corners + the parameter upload)."""
+        key = self._state_key()
+        if getattr(self, "_l2w_key", None) != key:
+            self._l2w, self._l2w_key = self._trs(), key
+        return self._l2w
+
+    def _trs(self) -> np.ndarray:
         x, y, z, w = [f32(v) for v in self.rotation]
         two = f32(2)
         one = f32(1)
@@ -99,7 +109,11 @@ class Transform:
 
     @property
     def worldToLocalMatrix(self) -> np.ndarray:
-        return np.linalg.inv(self.localToWorldMatrix.astype(np.float64)).astype(np.float32)
+        key = self._state_key()
+        if getattr(self, "_w2l_key", None) != key:
+            self._w2l = np.linalg.inv(self.localToWorldMatrix.astype(np.float64)).astype(np.float32)
+            self._w2l_key = key
+        return self._w2l
 
     def TransformPoint(self, p) -> np.ndarray:
         M = self.localToWorldMatrix
