@@ -313,8 +313,10 @@ class SlabEngine:
         # overlap: a frame packs its own face messages between the two launches of its last force kernel, and the
         # exchange for the NEXT frame runs while the rest of the frame is still on the GPU (sph_slab_arm_pack)
         self.overlap = bool(overlap)
-        if self.overlap and self.rebalance_every:
-            raise ValueError("overlap and moving cuts are not combined yet")
+        # overlap + moving cuts: a frame packs its messages itself, so the cuts of the NEXT build have to be known when
+        # the frame starts: a re-cut is planned at the end of one frame (from that frame's grid), used for the send
+        # range of the next frame's in-frame pack and applied at that frame's end (step_frame below)
+        self._cuts_next = None
         if self.adaptive and self.rebalance_every:
             raise ValueError("adaptive ghost width and moving cuts are not combined yet")
         self.band_misses = 0
@@ -457,27 +459,37 @@ class SlabEngine:
         # that moved since the last build (at most ghost/2 - 1 planes, the halo condition): width >= 2 ghost + shift.
         return 2 * self.ghost + self.max_cut_shift
 
-    def rebalance(self):
-        """Re-cut the slabs by particle count.  Collective (every rank calls it in the same frame); must run before
-        the frame's pack, while the grid of the last frame is still valid."""
-        rx, ry, rz, cap = self.grid
+    def _plan_recut(self, base_cuts):
+        """New cuts by particle count, at most max_cut_shift planes from `base_cuts`, or None if the shares are balanced
+        enough.  Collective (every rank calls it in the same frame); needs the grid of the last frame."""
+        rx = self.grid[0]
         hist = self.port.owned_plane_histogram(rx, self.keep[0], self.keep[1] - self.keep[0], self.own[0], self.own[1])
         hist = self.comm.allreduce_sum_array(hist)
         cum = np.concatenate([[0], np.cumsum(hist)])
-        shares = np.diff(cum[np.asarray(self.cuts)])
+        shares = np.diff(cum[np.asarray(base_cuts)])
         mean = max(float(cum[-1]) / self.world, 1.0)
         self.imbalance = float(shares.max()) / mean
         if self.imbalance <= self.rebalance_threshold:
-            return False
-        cuts = balanced_cuts(hist, self.cuts, self.min_width, self.max_cut_shift)
-        if cuts == self.cuts:
-            return False
-        self.cuts = cuts
+            return None
+        cuts = balanced_cuts(hist, base_cuts, self.min_width, self.max_cut_shift)
+        return None if cuts == list(base_cuts) else cuts
+
+    def _apply_cuts(self, cuts):
+        rx, ry, rz, cap = self.grid
+        self.cuts = list(cuts)
         x0, x1 = cuts[self.rank], cuts[self.rank + 1]
         self.own = (x0, x1)
         self.keep = self._keep_range()
         self.port.reconfigure(rx, self.keep[0], self.keep[1] - self.keep[0], ry, rz, cap, x0, x1)
         self.recuts += 1
+
+    def rebalance(self):
+        """Re-cut the slabs by particle count and apply it at once (classic order: must run before the frame's pack,
+        while the grid of the last frame is still valid).  Collective."""
+        cuts = self._plan_recut(self.cuts)
+        if cuts is None:
+            return False
+        self._apply_cuts(cuts)
         return True
 
     def set_params(self, p):
@@ -512,6 +524,7 @@ class SlabEngine:
         self.n = mine.shape[0]
         self.e.n = self.n
         self._primed = False          # overlap mode: the next frame gets its ghosts the classic way
+        self._cuts_next = None
         self.repartitions = getattr(self, "repartitions", 0) + 1
 
     def _distribute(self):
@@ -554,7 +567,8 @@ class SlabEngine:
     # ---- the per-frame exchange
     def exchange(self):
         t0 = time.perf_counter()
-        if self.rebalance_every and self.world > 1 and self.frames > 0 and self.frames % self.rebalance_every == 0:
+        if (self.rebalance_every and self.world > 1 and self.frames > 0 and self.frames % self.rebalance_every == 0
+                and not self.overlap):
             self.rebalance()
         # classic order: nothing is in flight, so the widths agreed on from LAST frame's needs apply to this frame's
         # pack, keep range and grid at once
@@ -577,8 +591,8 @@ class SlabEngine:
             self.e.n = self.n
         self.n_built = self.n          # owned + ghosts as of the last grid build
 
-    def _send_range(self):
-        x0, x1 = self.own
+    def _send_range(self, cuts=None):
+        x0, x1 = self.own if cuts is None else (cuts[self.rank], cuts[self.rank + 1])
         return (x0 + self.ws[0] if self.rank > 0 else 0,
                 x1 - self.ws[1] if self.rank < self.world - 1 else self.grid[0])
 
@@ -594,7 +608,7 @@ class SlabEngine:
         if not self._primed:
             self.exchange()                         # the very first frame needs its ghosts the classic way
             self._primed = True
-        left_below, right_from = self._send_range()
+        left_below, right_from = self._send_range(self._cuts_next)      # what the NEXT build's owners and ghosts need
         self.port.arm_pack(left_below, right_from, self.band_margin)
         self.e.step_frame(sub_steps, time_step)     # returns once everything is enqueued (one sync: survivor count)
         self._refresh_count()
@@ -604,7 +618,14 @@ class SlabEngine:
         to_l, to_r = self.port.pack_wait()          # the band part of the frame is done; the GPU carries on
         self.band_fraction = getattr(self.e, "band_workgroups", 0) / max((self.n + 255) // 256, 1)
         self._note_shift(self.e.read_counter(abi.CTR_MAX_PLANE_SHIFT))
+        planned = None
+        if self.rebalance_every and self.frames > 0 and self.frames % self.rebalance_every == 0:
+            # from THIS frame's grid (still valid: the rebuild below invalidates it), relative to the cuts about to apply
+            planned = self._plan_recut(self._cuts_next or self.cuts)
         from_l, from_r = self.comm.exchange(to_l, to_r, need=self._needed())
+        if self._cuts_next is not None:          # the records just received were packed for these cuts
+            self._apply_cuts(self._cuts_next)
+        self._cuts_next = planned
         self._adapt(in_flight=True)              # the records just received were packed with the widths of this frame
         self.n = self.port.rebuild(self.keep[0], self.keep[1], from_l, from_r)   # enqueued behind the frame
         self.e.n = self.n
@@ -701,7 +722,7 @@ def bench_main(args, rank, local_rank, world):
     # SPH_BENCH_OVERLAP=0: classic order (pack after the frame, exchange before the next one) instead of the
     # in-frame pack whose exchange runs under the second half of the frame
     rebalance = int(os.environ.get("SPH_BENCH_REBALANCE", "0"))
-    overlap = os.environ.get("SPH_BENCH_OVERLAP", "1") != "0" and not rebalance
+    overlap = os.environ.get("SPH_BENCH_OVERLAP", "1") != "0"
     # 12 ghost planes: at the spawn density of configs 4/5 (7 x rest density) the first frames throw particles up to
     # 5 cell planes per frame (scripts/max_shift.py), and the halo condition is ghost >= 2 (1 + shift); 2-3 planes later
     ghost = int(os.environ.get("SPH_BENCH_GHOST", "12"))

@@ -205,6 +205,30 @@ def test_moving_boundary_cube_repartitions_and_equals_single_domain(tmp_path, or
 
 
 @pytest.mark.parametrize("world", [2, 3])
+def test_moving_cuts_with_overlapped_exchange_equal_single_domain(tmp_path, oracle_built, world):
+    """Moving cuts AND the overlapped exchange: a frame packs its own messages, so a re-cut is planned one frame ahead
+    (from the grid of the frame that just ran), steers the send range of the next frame's in-frame pack and is applied
+    at that frame's end.  Still the single-domain run bit for bit."""
+    frames = 9
+    from oracle.ora import Oracle
+    ref = Oracle()
+    sc = small_tank(ref)
+    sc.run(frames)
+    want = ref.download_particles()
+    n = want.shape[0]
+    mp.spawn(_worker, args=(world, _free_port(), frames, str(tmp_path), True, 4, 2, 1, True), nprocs=world, join=True)
+    recs = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)])
+    cuts = [np.load(tmp_path / f"cuts{r}.npy").tolist() for r in range(world)]
+    assert all(c == cuts[0] for c in cuts), "ranks disagree about the cuts"
+    assert cuts[0][-1] >= 1, "the cuts never moved: the test does not exercise a re-cut"
+    assert np.load(tmp_path / "counts0.npy").tolist() == [n] * frames
+    assert np.array_equal(np.sort(recs["id"]), np.arange(n, dtype=np.uint32))
+    got = abi.aos_from_records(recs[np.argsort(recs["id"])])
+    for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
+        assert np.array_equal(got[:, sl], want[:, sl]), "re-cut + overlapped slab run differs from the single-domain run"
+
+
+@pytest.mark.parametrize("world", [2, 3])
 def test_moving_cuts_equal_single_domain(tmp_path, oracle_built, world):
     """Load-balanced cuts: every 2 frames the ranks re-cut the planes by particle count (one all-reduce of the
     per-plane histogram) -- the faces move, particles change owner through the ordinary face messages, and the

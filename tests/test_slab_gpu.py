@@ -91,8 +91,8 @@ def test_slabs_equal_single_engine_bitwise(tmp_path, world, ghost, drop_phases):
         assert np.array_equal(got[:, sl], want[:, sl]), f"{world} slabs differ from one engine"
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_moving_cuts_equal_single_engine_bitwise(tmp_path, world):
+@pytest.mark.parametrize("world,overlap", [(2, False), (3, False), (2, True), (3, True)])
+def test_moving_cuts_equal_single_engine_bitwise(tmp_path, world, overlap):
     """Load-balanced cuts (sph_slab_plane_counts + sph_slab_configure between frames): the faces move every 2 frames,
     ownership changes hands through the ordinary face messages, the result stays that of one engine bit for bit."""
     frames, n = 9, 3000
@@ -103,7 +103,7 @@ def test_moving_cuts_equal_single_engine_bitwise(tmp_path, world):
     want = eng.download_particles()
     eng.destroy()
     n = want.shape[0]
-    mp.spawn(_worker, args=(world, _free_port(), frames, str(tmp_path), n, 4, False, 2), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), frames, str(tmp_path), n, 4, False, 2, 1, overlap), nprocs=world, join=True)
     recs = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)])
     meta = np.load(tmp_path / "meta0.npy")
     cuts = [np.load(tmp_path / f"cuts{r}.npy").tolist() for r in range(world)]
