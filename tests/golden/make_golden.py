@@ -159,8 +159,13 @@ CASES = [
     ("bin_overflow_600_f1", overflow_scene, 1),
     ("escaped_obb_sphere_2000_f2", escaped_scene, 2),
     ("rotated_cube_2048_f3", rotated_cube_scene, 3),
+    # BASELINE config 3 in small: the cube rocks (the frame runs with LAST frame's grid against THIS frame's matrices,
+    # SPH.cs:176-185) while the sphere orbits through the fluid on the floor (compute:467-483)
+    ("config3_rocking_sphere_3000_f26", lambda e: scenes.config3(e, n=3000, scale=0.25), 26),
 ]
 
 if __name__ == "__main__":
+    only = set(sys.argv[1:])                  # optional: names of the cases to (re)write
     for name, builder, warm in CASES:
-        capture(name, builder, warm)
+        if not only or name in only:
+            capture(name, builder, warm)
