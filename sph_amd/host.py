@@ -54,7 +54,7 @@ def quat_from_axis_angle(axis, degrees) -> np.ndarray:
     """Quaternion.AngleAxis(degrees, axis) as (x, y, z, w)."""
     a = np.asarray(axis, dtype=np.float64)
     a = a / np.linalg.norm(a)
-    half = math.radians(float(degrees)) * 0.5
+    half = float(degrees) * math.pi / 180.0 * 0.5      # same operation order as host/sph_host.hpp (AngleAxis)
     s = math.sin(half)
     return np.array([a[0] * s, a[1] * s, a[2] * s, math.cos(half)], dtype=np.float32)
 
@@ -111,9 +111,29 @@ class Transform:
     def worldToLocalMatrix(self) -> np.ndarray:
         key = self._state_key()
         if getattr(self, "_w2l_key", None) != key:
-            self._w2l = np.linalg.inv(self.localToWorldMatrix.astype(np.float64)).astype(np.float32)
-            self._w2l_key = key
+            self._w2l, self._w2l_key = self._affine_inverse(self.localToWorldMatrix), key
         return self._w2l
+
+    @staticmethod
+    def _affine_inverse(M) -> np.ndarray:
+        """Inverse of the affine TRS matrix by the adjugate of its 3 x 3 part, in double, rounded once -- the same
+        operations in the same order as host/sph_host.hpp (Transform::worldToLocalMatrix), so that the Python and the
+        C++ host hand the kernels the same bits (a LAPACK inverse differs in the last place now and then, and one
+        OBB collision later two runs of a chaotic tank have parted)."""
+        a = [float(M[r, c]) for r in range(3) for c in range(3)]
+        det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6])
+        inv = [(a[4] * a[8] - a[5] * a[7]) / det, (a[2] * a[7] - a[1] * a[8]) / det, (a[1] * a[5] - a[2] * a[4]) / det,
+               (a[5] * a[6] - a[3] * a[8]) / det, (a[0] * a[8] - a[2] * a[6]) / det, (a[2] * a[3] - a[0] * a[5]) / det,
+               (a[3] * a[7] - a[4] * a[6]) / det, (a[1] * a[6] - a[0] * a[7]) / det, (a[0] * a[4] - a[1] * a[3]) / det]
+        out = np.zeros((4, 4), dtype=np.float32)
+        for r in range(3):
+            t = 0.0
+            for c in range(3):
+                out[r, c] = inv[r * 3 + c]
+                t -= inv[r * 3 + c] * float(M[c, 3])
+            out[r, 3] = t
+        out[3, 3] = 1
+        return out
 
     def TransformPoint(self, p) -> np.ndarray:
         M = self.localToWorldMatrix
@@ -179,7 +199,9 @@ class RockingMotion:
 
     def Update(self):
         theta = self.amplitude_deg * math.sin(self.rate * self.time.time)
-        self.transform.rotation = quat_from_axis_angle(self.axis, theta)
+        # Quaternion.AngleAxis takes a FLOAT angle: rounded here like in the C++ and C# hosts (the three must hand the
+        # kernels the same matrices: one differing bit parts two runs at their first OBB collision)
+        self.transform.rotation = quat_from_axis_angle(self.axis, float(f32(theta)))
 
 
 # --------------------------------------------------------------------------------------------

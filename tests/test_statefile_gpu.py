@@ -1,6 +1,7 @@
 """Raw-state files and the device render feed through the C ABI.  -m gpu."""
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before libsph_hip is loaded: torch ships its own HIP runtime, and two in one process do not share the GPU)
 
 from sph_amd import abi, scenes, statefile
 from tests.test_statefile import _resume_case

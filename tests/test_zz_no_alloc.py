@@ -4,6 +4,7 @@ input; the scratch keeps the first call's contents in between.  Collected last (
 pytest -x.  -m gpu."""
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before libsph_hip is loaded: torch ships its own HIP runtime, and two in one process do not share the GPU)
 
 from sph_amd import abi
 
