@@ -154,3 +154,39 @@ def test_full_step_between_density_and_force_is_seen_by_the_force_kernel():
             e.dispatch(k, e.cells if k == abi.K_CLEAR_GRID else n)
     assert_fields_close(eng.download_particles(), ora.download_particles(), 1e-5)
     eng.destroy()
+
+
+def test_extreme_positions_hash_and_search_like_the_oracle():
+    """Positions far outside any grid: +-1e9, +-3e38, +-inf, NaN.  float -> int conversion saturates and maps NaN to 0
+    (v_cvt_i32_f32, D3D ftoi, the oracle's ftoi_sat), the hash clamps (compute:126), the unclamped search cell
+    (compute:155) finds no cell in range.  Hash, bins, neighbour lists and counters must be the oracle's bit for bit; the
+    boundary pass then brings the finite ones back into the box."""
+    se, so, eng, ora = _pair(lambda e: scenes.config1(e, n=4096))
+    se.sph.use_step_frame = True
+    se.start()
+    so.start()
+    state = ora.download_particles()
+    big = [1e9, -1e9, 3e38, -3e38, np.inf, -np.inf, np.nan, 2147483648.0 * 0.25 - 5.0]
+    k = 0
+    for axis in range(3):
+        for v in big:
+            state[100 + k, axis] = v
+            k += 1
+    ora.upload_particles(state)
+    eng.upload_particles(state)
+    for e in (eng, ora):                           # grid build on the uploaded positions, kernel by kernel
+        e.set_phase_table(se.sph._phase_rows())
+        e.apply_phase_table()
+        e.dispatch(abi.K_CLEAR_GRID, e.cells)
+        e.dispatch(abi.K_BUILD_GRID, e.n)
+    assert_grid_equal(eng.download_grid(), ora.download_grid(with_counts=True), so.sph.maxParticlesPerCell)
+    assert_neighbors_equal(eng, ora, 512)
+    assert eng.read_counter(abi.CTR_OUT_OF_GRID) == ora.read_counter(abi.CTR_OUT_OF_GRID) >= 21
+    se.frame()
+    so.frame()
+    assert_grid_equal(eng.download_grid(), ora.download_grid(with_counts=True), so.sph.maxParticlesPerCell)
+    got, want = eng.download_particles(), ora.download_particles()
+    fin = np.isfinite(want).all(axis=1)
+    assert np.array_equal(np.isfinite(got).all(axis=1), fin)
+    assert_fields_close(got[fin], want[fin], 1e-5)
+    eng.destroy()
