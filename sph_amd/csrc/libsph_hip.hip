@@ -150,7 +150,7 @@ struct sph_ctx {
     // every second frame does not -- the host catches up on the untimed frames.
     int timingStride = 2;
     unsigned eventFlags = hipEventDisableSystemFence;   // SPH_HIP_EVENT_FENCE=1: default events (A/B)
-    int framesSinceHarvest = 0;         // level 1 records events on every kTimingStride-th frame only
+    int framesSinceHarvest = 0;         // level 1 times every timingStride-th frame, counted from the last sph_get_timings
     int framesTimed = 0;
 };
 

@@ -53,7 +53,8 @@ __device__ __forceinline__ SlabRecord make_record(const StateSet& st, int s) {
 
 // Records arrive with a phase id.  The packed neighbour records of the force kernel (PackedNbr) take
 // mass and viscosity from the phase table, which is only right if every record's own values ARE its
-// phase's row: any record that disagrees raises a sticky flag that switches that path off.
+// phase's row: any record that disagrees raises a sticky flag; the host reads it with the survivor count of the next grid
+// build and launches the three-gather mode of the force kernel (and the 16-byte candidates of the density kernel).
 struct PhaseCheck {
     const sph_phase* table;   // null = no table set
     int rows;
