@@ -126,3 +126,27 @@ def test_csharp_binding_matches_header():
     kern = re.search(r"enum SphKernel\s*\{(.*?)\}", src, flags=re.S).group(1)
     ids = dict((k.strip(), int(v)) for k, v in (kv.split("=") for kv in kern.replace("\n", " ").split(",")))
     assert [k for k, _ in sorted(ids.items(), key=lambda kv: kv[1])] == [n[3:] for n in abi.KERNEL_NAMES]
+
+
+def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
+    """The boundary is a C ABI: include/sph_hip.h must compile as C99 (no C++ or HIP types), and a C program that
+    references every declared entry point must link against libsph_hip.so with gcc alone."""
+    import subprocess
+    header = os.path.join(ROOT, "include", "sph_hip.h")
+    names = declared_functions()
+    src = tmp_path / "uses_abi.c"
+    src.write_text('#include "sph_hip.h"\n#include <stdio.h>\n'
+                   "typedef void (*fn_t)(void);\nint main(void) {\n    fn_t fns[] = {" + ", ".join(f"(fn_t){n}" for n in names) + "};\n"
+                   "    sph_params p; p.struct_size = (uint32_t)sizeof p;\n"
+                   '    printf("%u %u %d %s\\n", (unsigned)(sizeof fns / sizeof fns[0]), p.struct_size, (int)sizeof(sph_slab_record), sph_version());\n'
+                   "    return 0;\n}\n")
+    exe = tmp_path / "uses_abi"
+    lib_dir = os.path.join(ROOT, "sph_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.dirname(header), str(src), "-o", str(exe),
+                        "-L", lib_dir, "-l:libsph_hip.so", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True)          # sph_version needs no GPU
+    assert out.returncode == 0, out.stderr
+    n, size, rec, _ = out.stdout.split(None, 3)
+    assert int(n) == len(names) and int(size) == C.sizeof(abi.SphParams) and int(rec) == abi.SLAB_RECORD_BYTES
