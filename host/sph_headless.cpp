@@ -57,7 +57,11 @@ int main(int argc, char** argv) {
         SPH sph(0);
         common(sph);
         sph.useStepFrame = stepFrame;
-        const Color WATER{0.2f, 0.5f, 1.0f, 0.8f}, OIL{1.0f, 0.8f, 0.2f, 0.8f};
+        const Color WATER{0.2f, 0.5f, 1.0f, 0.8f}, OIL{1.0f, 0.8f, 0.2f, 0.8f};      // the BASELINE configurations
+        // SpawnBox.particleColor as serialized in the scenes (Scene1.unity:543, Scene2.unity:499/594, Scene3.unity:543,
+        // Scene4.unity:499/594)
+        const float blueG[5] = {0.5f, 0.18861637f, 0.30632228f, 0.21572512f, 0.23613732f};
+        const Color BLUE{0.0039215684f, blueG[scene >= 1 && scene <= 4 ? scene : 0], 1.0f, 1.0f}, YELLOW{1.0f, 0.94675124f, 0.0f, 1.0f};
         const float ls = (float)std::pow(scale, 1.0 / 3.0);
         auto cnt = [&](int c) { int v = (int)std::lround(c * scale); return v < 1 ? 1 : v; };
         auto sz = [&](double x, double y, double z) { return Vector3{(float)(x * (double)std::pow(scale, 1.0 / 3.0)), (float)(y * (double)std::pow(scale, 1.0 / 3.0)), (float)(z * (double)std::pow(scale, 1.0 / 3.0))}; };
@@ -69,12 +73,12 @@ int main(int argc, char** argv) {
             sph.boundaryCube = &so.cube; sph.obstacleCollider = &so.obstacle;
             if (scene <= 2) { sph.surfaceTensionCoefficient = 0.1f; sph.xsphEpsilon = 0.3f; }
             else { sph.surfaceTensionCoefficient = 0.01f; sph.xsphEpsilon = 0.2f; }
-            if (scene == 1) addBox(so, cnt(200000), sz(5, 10, 5), 20, 0.1f, 0.2f, WATER, {0, 20, 0});
-            else if (scene == 2) { addBox(so, cnt(150000), sz(5, 10, 5), 20, 0.01f, 0.2f, WATER, {0, 20, 5});
-                                   addBox(so, cnt(75000), sz(5, 10, 5), 10, 0.1f, 0.2f, OIL, {0, 20, -5}); }
-            else if (scene == 3) addBox(so, cnt(200000), sz(10, 10, 10), 20, 0.1f, 0.2f, WATER, {0, 15, 0});
-            else if (scene == 4) { addBox(so, cnt(150000), sz(5, 10, 5), 20, 0.1f, 0.2f, WATER, {0, 15, 5});
-                                   addBox(so, cnt(75000), sz(5, 10, 5), 10, 0.1f, 0.2f, OIL, {0, 15, -5}); }
+            if (scene == 1) addBox(so, cnt(200000), sz(5, 10, 5), 20, 0.1f, 0.2f, BLUE, {0, 20, 0});
+            else if (scene == 2) { addBox(so, cnt(150000), sz(5, 10, 5), 20, 0.01f, 0.2f, BLUE, {0, 20, 5});
+                                   addBox(so, cnt(75000), sz(5, 10, 5), 10, 0.1f, 0.2f, YELLOW, {0, 20, -5}); }
+            else if (scene == 3) addBox(so, cnt(200000), sz(10, 10, 10), 20, 0.1f, 0.2f, BLUE, {0, 15, 0});
+            else if (scene == 4) { addBox(so, cnt(150000), sz(5, 10, 5), 20, 0.1f, 0.2f, BLUE, {0, 15, 5});
+                                   addBox(so, cnt(75000), sz(5, 10, 5), 10, 0.1f, 0.2f, YELLOW, {0, 15, -5}); }
             else { fprintf(stderr, "scene 1..4\n"); return 2; }
             if (scene >= 3) {
                 CircularMotion m; m.transform = &so.obstacle.transform; m.time = &so.time; m.center = {0, 0, 0};

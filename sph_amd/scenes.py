@@ -6,8 +6,13 @@ from __future__ import annotations
 
 from .host import (SPH, CircularMotion, RockingMotion, Scene, SpawnBox, SphereCollider, Time, Transform)
 
-WATER = (0.2, 0.5, 1.0, 0.8)
+WATER = (0.2, 0.5, 1.0, 0.8)                   # the BASELINE configurations (build-defined scenes)
 OIL = (1.0, 0.8, 0.2, 0.8)
+# SpawnBox.particleColor as serialized in the reference's scenes (Scene1.unity:306, Scene2.unity:316/411,
+# Scene3.unity:306, Scene4.unity:499/594; tests/golden/unity_scene_values.json holds every serialized value)
+SCENE_BLUE = {1: (0.0039215684, 0.18861637, 1.0, 1.0), 2: (0.0039215684, 0.30632228, 1.0, 1.0),
+              3: (0.0039215684, 0.21572512, 1.0, 1.0), 4: (0.0039215684, 0.23613732, 1.0, 1.0)}
+SCENE_YELLOW = (1.0, 0.94675124, 0.0, 1.0)
 
 # Inspector values shared by Scene1-4 (Scene1.unity:604-622 etc.)
 SCENE_COMMON = dict(soundSpeed=10.0, gamma=4.0, smoothingRadius=0.3, gravity=-9.81, timeStep=0.02, subSteps=1,
@@ -37,6 +42,7 @@ def unity_scene(engine, which: int, scale_count: float = 1.0, seed: int = 12345)
     def sz(x, y, z):
         return (x * ls, y * ls, z * ls)
     time = Time()
+    blue = SCENE_BLUE.get(which, WATER)
     cube = Transform(position=(0, 15, 0), localScale=(20, 30, 20))                # Scene1.unity:933-935
     obstacle = _parked_obstacle()
     movers = []
@@ -45,16 +51,16 @@ def unity_scene(engine, which: int, scale_count: float = 1.0, seed: int = 12345)
     else:
         sigma, eps = 0.01, 0.2
     if which == 1:
-        boxes = [SpawnBox(cnt(200000), sz(5, 10, 5), 20, 0.1, 0.2, particleColor=WATER, position=(0, 20, 0))]
+        boxes = [SpawnBox(cnt(200000), sz(5, 10, 5), 20, 0.1, 0.2, particleColor=blue, position=(0, 20, 0))]
     elif which == 2:
-        boxes = [SpawnBox(cnt(150000), sz(5, 10, 5), 20, 0.01, 0.2, particleColor=WATER, position=(0, 20, 5)),
-                 SpawnBox(cnt(75000), sz(5, 10, 5), 10, 0.1, 0.2, particleColor=OIL, position=(0, 20, -5))]
+        boxes = [SpawnBox(cnt(150000), sz(5, 10, 5), 20, 0.01, 0.2, particleColor=blue, position=(0, 20, 5)),
+                 SpawnBox(cnt(75000), sz(5, 10, 5), 10, 0.1, 0.2, particleColor=SCENE_YELLOW, position=(0, 20, -5))]
     elif which == 3:
-        boxes = [SpawnBox(cnt(200000), sz(10, 10, 10), 20, 0.1, 0.2, particleColor=WATER, position=(0, 15, 0))]
+        boxes = [SpawnBox(cnt(200000), sz(10, 10, 10), 20, 0.1, 0.2, particleColor=blue, position=(0, 15, 0))]
         movers.append(CircularMotion(obstacle.transform, time, center=(0, 0, 0), radius=5.0, speed=2.0))
     elif which == 4:
-        boxes = [SpawnBox(cnt(150000), sz(5, 10, 5), 20, 0.1, 0.2, particleColor=WATER, position=(0, 15, 5)),
-                 SpawnBox(cnt(75000), sz(5, 10, 5), 10, 0.1, 0.2, particleColor=OIL, position=(0, 15, -5))]
+        boxes = [SpawnBox(cnt(150000), sz(5, 10, 5), 20, 0.1, 0.2, particleColor=blue, position=(0, 15, 5)),
+                 SpawnBox(cnt(75000), sz(5, 10, 5), 10, 0.1, 0.2, particleColor=SCENE_YELLOW, position=(0, 15, -5))]
         movers.append(CircularMotion(obstacle.transform, time, center=(0, 0, 0), radius=5.0, speed=1.0))
     else:
         raise ValueError("scene 1..4")
@@ -146,3 +152,48 @@ def config5(engine, gpus=1, per_gpu=8388608, seed=12345, block=(80.0, 64.0), hei
     sph = SPH(engine, **f, surfaceTensionCoefficient=0.01, xsphEpsilon=0.2, boundaryCube=cube, obstacleCollider=None,
               spawnBoxes=boxes, seed=seed)
     return Scene(sph, Time(), [])
+
+
+def from_values(engine, values: dict, scale_count: float = 1.0, seed: int = 12345) -> Scene:
+    """A scene from a description in the schema of tests/golden/unity_scene_values.json (one entry of its "scenes":
+    what a Unity scene file serializes for the path): {"sph": {Inspector fields of SPH.cs:5-49}, "boundaryCube":
+    {position, rotation, localScale} | null, "obstacle": {radius, transform, mover: {center, radius, speed, enabled} |
+    null} | null, "spawnBoxes": [{particleCount, spawnSize, restDensity, viscosity, particleMass, initialVelocity,
+    particleColor, position}]}.  scale_count as in unity_scene."""
+    ls = float(scale_count) ** (1.0 / 3.0)
+    time = Time()
+    fields = {k: v for k, v in values["sph"].items() if k != "totalCells"}           # totalCells is computed (SPH.cs:79)
+    cube = None
+    if values.get("boundaryCube"):
+        c = values["boundaryCube"]
+        cube = Transform(position=c["position"], rotation=c.get("rotation", (0, 0, 0, 1)), localScale=c["localScale"])
+    obstacle, movers = None, []
+    if values.get("obstacle"):
+        o = values["obstacle"]
+        t = o["transform"]
+        obstacle = SphereCollider(radius=o["radius"], transform=Transform(position=t["position"],
+                                  rotation=t.get("rotation", (0, 0, 0, 1)), localScale=t["localScale"]))
+        m = o.get("mover")
+        if m and m.get("enabled", 1):
+            movers.append(CircularMotion(obstacle.transform, time, center=m["center"], radius=m["radius"], speed=m["speed"]))
+    boxes = []
+    for b in values["spawnBoxes"]:
+        if not (b.get("enabled", 1) and b.get("active", 1)):
+            continue
+        boxes.append(SpawnBox(max(1, int(round(b["particleCount"] * scale_count))), tuple(x * ls for x in b["spawnSize"]),
+                              b["restDensity"], b["viscosity"], b["particleMass"],
+                              initialVelocity=b.get("initialVelocity", (0, 0, 0)),
+                              particleColor=b.get("particleColor", (1, 1, 1, 1)), position=b["position"]))
+    sph = SPH(engine, **fields, boundaryCube=cube, obstacleCollider=obstacle, spawnBoxes=boxes, seed=seed)
+    return Scene(sph, time, movers)
+
+
+def load_scene(engine, path: str, name: str = None, **kw) -> Scene:
+    """from_values on a JSON file: either one scene description, or {"scenes": {name: description}} (then `name`
+    picks one)."""
+    import json
+    with open(path) as fh:
+        doc = json.load(fh)
+    if "scenes" in doc:
+        doc = doc["scenes"][name]
+    return from_values(engine, doc, **kw)

@@ -86,7 +86,8 @@ def test_ply_round_trip_and_splat(tmp_path, oracle_built):
     v = statefile.read_ply_vertices(path)
     assert v.shape[0] == aos.shape[0]
     assert np.array_equal(v["x"], aos[:, 0]) and np.array_equal(v["z"], aos[:, 2]) and np.array_equal(v["density"], aos[:, 9])
-    assert set(np.unique(v["red"])) == {int(0.2 * 255 + 0.5), 255}          # WATER and OIL of scenes.py
+    # Scene2's own colours (Scene2.unity:499, 594): r = 0.0039215684 (1/255) and 1
+    assert set(np.unique(v["red"])) == {int(scenes.SCENE_BLUE[2][0] * 255 + 0.5), 255} == {1, 255}
     img = statefile.splat_png(str(tmp_path / "front.png"), aos, lo=(-10, 0, -10), hi=(10, 30, 10), width=200)
     assert img.shape == (300, 200, 3)
     lit = (img != np.array([16, 16, 24], dtype=np.uint8)).any(axis=2)
