@@ -1,0 +1,157 @@
+"""Seeded random scenes, engine against oracle in lock-step.  -m gpu.
+
+The fixed scenes all share the reference's Inspector values (h 0.3, cell 0.25, mass 0.2, two phases, gamma 4).  Every
+one of those is Inspector-editable in the reference (SPH.cs:5-49, SpawnBox.cs:7-23), and the engine chooses between code
+paths by them (uniform-mass 12-byte candidates, packed neighbour records for <= 4 phases, 27-range walk once a bin
+overflowed, OBB / AABB boundary, obstacle on / off, sub-steps).  The cases below draw all of them at random (fixed seeds:
+the cases are the same on every run) and hold every frame to the usual bar: hash, sorted ids, ranges, neighbour lists and
+counters bit-exact, fields within 1e-5 x field scale.
+
+Frames of several sub-steps run without re-synchronisation between the sub-steps, and some of the scenes drawn here are
+violent (spawned at many times their rest density with h 0.2): the oracle's OWN output then moves by far more than 1e-5
+when its input positions move by one ulp (seed 13: 1.6e-7 -> 9.6e-6 -> 3.6e-3 of the position scale after 1, 2, 3
+sub-steps).  A sub-stepped frame is therefore held to max(1e-5, 8 x that measured one-ulp sensitivity) per field group;
+frames of one sub-step, and every integer artefact, stay at the plain bar."""
+import numpy as np
+import pytest
+
+from sph_amd import abi
+from sph_amd.host import (SPH, CircularMotion, Scene, SpawnBox, SphereCollider, Time, Transform, quat_from_axis_angle)
+from tests.util import POS, VEL, ACC, DENS, PRES, assert_fields_close, assert_grid_equal, assert_neighbors_equal, field_scale
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _draw(seed):
+    """The description of a random scene (plain values, so that engine and oracle get identical ones)."""
+    r = np.random.default_rng(1000 + seed)
+    d = {}
+    d["h"] = float(r.choice([0.2, 0.3, 0.35, 0.5]))
+    use_cube = bool(r.random() < 0.65)
+    size = r.uniform(3.0, 7.0, 3)
+    d["cube"] = None
+    if use_cube:
+        axis = r.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        d["cube"] = dict(position=r.uniform(-1, 1, 3).tolist(), axis=axis.tolist(), angle=float(r.uniform(0, 35)) * float(r.random() < 0.7),
+                         scale=size.tolist())
+        centre = np.array(d["cube"]["position"])
+    else:
+        centre = r.uniform(-1, 1, 3)
+    d["boundsCenter"], d["boundsSize"] = centre.tolist(), size.tolist()
+    d["gridResolution"] = int(r.integers(9, 33))            # cell size = min extent / resolution: 0.1 .. 0.7, coarser AND finer than h
+    d["cap"] = int(r.choice([3, 12, 500]))                  # small caps: bins overflow (rule O2), 27-range walk
+    d["gamma"] = float(r.choice([1.0, 4.0, 7.0]))
+    d["soundSpeed"] = float(r.uniform(4, 20))
+    d["gravity"] = float(r.choice([-9.81, 0.0, 3.0]))
+    d["timeStep"] = float(r.uniform(0.004, 0.02))
+    d["subSteps"] = int(r.choice([1, 1, 2, 3]))
+    d["sigma"], d["sigmaThr"] = float(r.choice([0.0, 0.01, 0.2])), float(r.choice([0.0, 0.01, 0.5]))
+    d["eps"] = float(r.choice([0.0, 0.2, 0.5]))
+    d["stiff"], d["damp"] = float(r.uniform(10, 500)), float(r.choice([1.0, 0.999, 0.9]))
+    n_boxes = int(r.choice([1, 2, 3, 4, 5, 7]))             # > 4 phases: no packed records
+    uniform_mass = bool(r.random() < 0.5)
+    total = int(r.integers(600, 5000))
+    boxes = []
+    for b in range(n_boxes):
+        ext = r.uniform(0.25, 0.6, 3) * size
+        pos = centre + r.uniform(-0.3, 0.3, 3) * size       # partly outside the boundary now and then: clamped hash, push-back
+        boxes.append(dict(count=max(1, total // n_boxes + int(r.integers(-20, 20))), size=ext.tolist(), rho0=float(r.uniform(5, 30)),
+                          visc=float(r.uniform(0.01, 0.3)), mass=0.2 if uniform_mass else float(r.uniform(0.1, 0.3)),
+                          vel=(r.uniform(-3, 3, 3) * float(r.random() < 0.5)).tolist(), color=r.random(4).tolist(), pos=pos.tolist()))
+    d["boxes"] = boxes
+    d["obstacle"] = None
+    if r.random() < 0.5:
+        d["obstacle"] = dict(pos=(centre + r.uniform(-0.2, 0.2, 3) * size).tolist(), scale=float(r.uniform(0.5, 2.5)),
+                             moving=bool(r.random() < 0.5), orbit=float(r.uniform(0.3, 1.5)), speed=float(r.uniform(0.5, 4.0)))
+    d["step_frame"] = bool(r.random() < 0.6)
+    d["seed"] = int(r.integers(1, 1 << 30))
+    return d
+
+
+def _build(e, d):
+    time = Time()
+    cube = None
+    if d["cube"]:
+        c = d["cube"]
+        cube = Transform(position=c["position"], rotation=quat_from_axis_angle(c["axis"], c["angle"]), localScale=c["scale"])
+    obstacle, movers = None, []
+    if d["obstacle"]:
+        o = d["obstacle"]
+        obstacle = SphereCollider(radius=0.5, transform=Transform(position=o["pos"], localScale=(o["scale"],) * 3))
+        if o["moving"]:
+            movers.append(CircularMotion(obstacle.transform, time, center=o["pos"], radius=o["orbit"], speed=o["speed"]))
+    boxes = [SpawnBox(b["count"], b["size"], b["rho0"], b["visc"], b["mass"], initialVelocity=b["vel"], particleColor=b["color"],
+                      position=b["pos"]) for b in d["boxes"]]
+    sph = SPH(e, soundSpeed=d["soundSpeed"], gamma=d["gamma"], smoothingRadius=d["h"], gravity=d["gravity"], timeStep=d["timeStep"],
+              subSteps=d["subSteps"], surfaceTensionCoefficient=d["sigma"], surfaceTensionThreshold=d["sigmaThr"], xsphEpsilon=d["eps"],
+              boundsCenter=d["boundsCenter"], boundsSize=d["boundsSize"], boundaryCube=cube, obstacleCollider=obstacle,
+              obstacleRepulsionStiffness=d["stiff"], particleCollisionDamping=d["damp"], maxParticlesPerCell=d["cap"],
+              gridResolution=d["gridResolution"], spawnBoxes=boxes, seed=d["seed"])
+    sph.use_step_frame = d["step_frame"]
+    return Scene(sph, time, movers)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_scene_lockstep(seed):
+    from oracle.ora import Oracle
+    d = _draw(seed)
+    eng, ora = abi.Engine(0), Oracle()
+    se, so = _build(eng, d), _build(ora, d)
+    se.start()
+    so.start()
+    frames = 4
+    seen_overflow = 0
+    probe = sp = None
+    if d["subSteps"] > 1:                                   # the oracle again, on inputs one ulp off: the frame's conditioning
+        probe = Oracle()
+        sp = _build(probe, d)
+        sp.start()
+    rng = np.random.default_rng(seed)
+    for f in range(frames):
+        state = ora.download_particles()
+        eng.upload_particles(state)
+        if probe:
+            off = state.copy()
+            off[:, POS] = np.nextafter(off[:, POS], np.where(rng.random((len(off), 3)) < 0.5, -np.inf, np.inf).astype(np.float32))
+            probe.upload_particles(off)
+            sp.frame()
+        se.frame()
+        so.frame()
+        what = f"seed {seed} frame {f}: "
+        cap = so.sph.maxParticlesPerCell
+        assert_grid_equal(eng.download_grid(), ora.download_grid(with_counts=True), cap, what)
+        # neighbour lists as the reference's loops see them (the first `cap` ids of a bin); 1,024 slots hold the densest case
+        assert_neighbors_equal(eng, ora, 1024, what)
+        got, want = eng.download_particles(), ora.download_particles()
+        if probe:
+            moved = probe.download_particles()
+            for name, sl in (("pos", POS), ("vel", VEL), ("acc", ACC), ("density", DENS), ("pressure", PRES)):
+                scale = field_scale(want[:, sl])
+                sens = float(np.max(np.abs(moved[:, sl].astype(np.float64) - want[:, sl]))) / scale
+                tol = max(TOL, 8.0 * sens)
+                err = float(np.max(np.abs(got[:, sl].astype(np.float64) - want[:, sl])))
+                assert err <= tol * scale, f"{what}{name}: {err / scale:.2e} of the field scale > {tol:.2e} (one-ulp sensitivity {sens:.2e})"
+            assert np.array_equal(got[:, 11:18], want[:, 11:18]), what + "static fields"
+        else:
+            assert_fields_close(got, want, TOL, what)
+        ctr = [ora.read_counter(k) for k in range(3)]
+        assert [eng.read_counter(k) for k in range(3)] == ctr, what + "counters"
+        seen_overflow += ctr[1]
+    eng.destroy()
+    ora.destroy()
+    if probe:
+        probe.destroy()
+
+
+def test_the_random_cases_reach_the_paths_they_are_for():
+    """The draw is only worth its name if the cases differ where the engine branches (CPU-cheap, but kept with its cases)."""
+    ds = [_draw(s) for s in range(24)]
+    assert any(len(d["boxes"]) > 4 for d in ds) and any(len(d["boxes"]) == 1 for d in ds)
+    assert any(len({b["mass"] for b in d["boxes"]}) > 1 for d in ds) and any(len({b["mass"] for b in d["boxes"]}) == 1 for d in ds)
+    assert any(d["cube"] and d["cube"]["angle"] > 0 for d in ds) and any(d["cube"] is None for d in ds)
+    assert any(d["cap"] == 3 for d in ds) and any(d["subSteps"] > 1 for d in ds)
+    assert any(d["obstacle"] and d["obstacle"]["moving"] for d in ds)
+    assert any(d["step_frame"] for d in ds) and any(not d["step_frame"] for d in ds)
