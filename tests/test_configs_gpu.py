@@ -5,6 +5,7 @@ through the C ABI.  -m gpu.
             current matrices, SPH.cs:176-185, 303-346) + orbiting sphere obstacle (SphereMover.cs:12-21,
             compute:467-483), 32 frames, kernel-by-kernel dispatch and sph_step_frame;
   configs 2 and 3 at FULL size (262,144 / 1,048,576 particles) against the OpenMP build of the oracle;
+  the largest single-GPU sizes (config 5's 8,388,608-particle block, config 4's 16,777,216 particles), one frame;
   configs 4 and 5 in test-size geometry (scenes.CONFIG4_SMALL / CONFIG5_SMALL: same layout, same spawn densities):
             one engine, and 2 and 4 slab ranks sharing the GPU -- every frame all ranks restart from the ORACLE's
             (single-domain) state and their owned particles are compared with the oracle's next state.
@@ -89,6 +90,23 @@ def test_full_size_lockstep_against_openmp_oracle(which, n):
     assert all(s["overflow"] == 0 for s in stats)
     if which == "config3":
         assert len({s["grid"] for s in stats}) >= 2, "config 3 never regridded"
+
+
+@pytest.mark.parametrize("which,n", [("config5", 8388608), ("config4", 16777216)])
+def test_largest_single_gpu_sizes_one_frame_against_openmp_oracle(which, n):
+    """The sizes the multi-GPU configurations put on ONE GPU: config 5's per-GPU block (8,388,608 particles, 31 M cells)
+    and the whole of config 4 (16,777,216 particles, 49 M cells), one lock-step frame from the spawn state against the
+    OpenMP oracle: hash, sorted ids and ranges bit-exact, density bit-identical, fields in tolerance.  Neighbour lists
+    are not exported at this size (n x 224 ints each side); a bit-identical density sum over the bit-identical order is
+    the same statement.  The bin capacity is 64 instead of the scenes' 500 on both sides -- nothing overflows (asserted;
+    at most ~30 particles share a cell), so the results are the same, and the oracle's reference-shaped
+    GridIndices[cells x cap] stays at 8-13 GB of address space instead of 63-98."""
+    def builder(e):
+        sc = scenes.config5(e, gpus=1, per_gpu=n) if which == "config5" else scenes.config4(e, n=n)
+        sc.sph.maxParticlesPerCell = 64
+        return sc
+    stats = _lockstep(builder, 1, True, omp=True, check_nb=False, exact_density=True)
+    assert stats[0]["overflow"] == 0 and stats[0]["out_of_grid"] == 0
 
 
 # ---------------------------------------------------------------------------------------------- configs 4, 5: one engine
