@@ -181,7 +181,10 @@ int  sph_set_phase_table(sph_ctx* ctx, const sph_phase* table, int n_phases);
 /* particleSpawnBoxIndices (SPH.cs:75, 276): one phase index per particle id. */
 int  sph_set_phase_ids(sph_ctx* ctx, const uint8_t* ids, int n);
 /* Applies table[phase[id]] to restDensity/viscosity/mass/color of every particle now
- * (what UpdateParticleStaticProperties does each frame). */
+ * (what UpdateParticleStaticProperties does each frame).  Slab mode: the phase is kept per slot (sph_slab_record.phase)
+ * and a table in force is authoritative, as the spawn boxes are in the reference -- the local slots (owned and ghost)
+ * take their rows here, records stored later (sph_slab_upload, sph_slab_rebuild) take theirs when they are stored, so a
+ * live edit made on every rank reaches every particle; a phase beyond the table keeps the record's own values. */
 int  sph_apply_phase_table(sph_ctx* ctx);
 
 /* ---- dispatch -------------------------------------------------------------------------- */

@@ -359,8 +359,28 @@ int harvestSlot(sph_ctx* c, int slot) {
     return SPH_OK;
 }
 
+StateSet curSet(sph_ctx* c) {
+    StateSet s = c->set[c->cur];
+    s.velV = c->set[c->velCur].velV;
+    return s;
+}
+
 int applyPhaseTable(sph_ctx* c) {
-    if (!c->staticDirty || c->slab) return SPH_OK;   // slab records carry their static properties
+    if (!c->staticDirty) return SPH_OK;
+    if (c->slab) {
+        // live edit of a spawn box in slab mode: every local slot (owned and ghost) takes its phase's row; records
+        // that arrive later take theirs when they are stored (store_record).  Every rank applies the same table.
+        const StateSet st = curSet(c);
+        if (!c->phaseTable.empty() && c->n > 0 && st.phase) {
+            hipLaunchKernelGGL(k_apply_phase_table_slots, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->n, st,
+                               (const sph_phase*)c->phaseTableDev, (int)c->phaseTable.size());
+            CHECK_LAUNCH(c);
+            c->packedValid = false;     // the records the density kernel packed carry nothing static, but stay on the safe side
+        }
+        c->staticDirty = false;
+        c->slabPackedOff = false;       // local slots and table agree again
+        return SPH_OK;
+    }
     if (c->phaseTable.empty() || !c->havePhaseIds) { c->staticDirty = false; return SPH_OK; }
     hipLaunchKernelGGL(k_apply_phase_table, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->n,
                        StateSet{c->set[c->cur].posM, c->set[c->velCur].velV, c->set[c->cur].acc,
@@ -369,12 +389,6 @@ int applyPhaseTable(sph_ctx* c) {
     CHECK_LAUNCH(c);
     c->staticDirty = false;
     return SPH_OK;
-}
-
-StateSet curSet(sph_ctx* c) {
-    StateSet s = c->set[c->cur];
-    s.velV = c->set[c->velCur].velV;
-    return s;
 }
 
 // CS_ClearGrid (compute:104-111): a bin is a range of the cumulative table here, so clearing = zeroing
@@ -853,8 +867,8 @@ int sph_set_phase_table(sph_ctx* c, const sph_phase* table, int n_phases) {
         return SPH_OK;   // unchanged since last frame: nothing to re-apply
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    // slab records carry their own static properties: a table that changes under them no longer
-    // describes them (no live phase edits in slab mode), so the packed neighbour records go off
+    // slab mode: until sph_apply_phase_table has rewritten the local slots, the table no longer describes them, so
+    // the packed neighbour records (mass / viscosity looked up by phase) stay off
     if (c->slab && c->n > 0) c->slabPackedOff = true;
     if ((int)c->phaseTable.size() != n_phases) {
         devFree(c->phaseTableDev);
@@ -884,7 +898,7 @@ int sph_set_phase_ids(sph_ctx* c, const uint8_t* ids, int n) {
 
 int sph_apply_phase_table(sph_ctx* c) {
     if (!c) return SPH_E_INVALID;
-    if (c->n <= 0) return fail(c, SPH_E_STATE, "no particles allocated");
+    if (c->n <= 0 && !c->slab) return fail(c, SPH_E_STATE, "no particles allocated");   // an empty slab is a valid state
     HIP_TRY(c, hipSetDevice(c->device));
     return applyPhaseTable(c);
 }

@@ -929,6 +929,20 @@ __global__ __launch_bounds__(kBlock) void k_apply_phase_table(int n, StateSet st
     color[id] = make_float4(ph.color[0], ph.color[1], ph.color[2], ph.color[3]);
 }
 
+// The same refresh in slab mode: phases are kept per SLOT there (ids are global, a slab holds a subset), colours are
+// not part of a slab's state.  Slots whose phase the table does not know keep their values.
+__global__ __launch_bounds__(kBlock) void k_apply_phase_table_slots(int n, StateSet st, const sph_phase* __restrict__ table,
+                                                                    int rows) {
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    const int p = st.phase[s];
+    if (p >= rows) return;
+    const sph_phase ph = table[p];
+    st.rho0[s] = ph.restDensity;
+    st.velV[s].w = ph.viscosity;
+    st.posM[s].w = ph.mass;
+}
+
 // Neighbour-list export (parity only): what CS_DensityPressure's loop accepts right now, walked the
 // same way the production kernels walk it (row ranges when no bin overflowed, capped cells otherwise).
 __global__ __launch_bounds__(kBlock) void k_export_neighbors(DevParams P, const float4* __restrict__ posM,

@@ -63,19 +63,24 @@ struct PhaseCheck {
 
 __device__ __forceinline__ void store_record(const StateSet& st, int k, const SlabRecord& r, const PhaseCheck& pc) {
     if (st.phase) st.phase[k] = (uint8_t)(r.phase & 255u);
+    float mass = r.posM.w, visc = r.velV.w, rho0 = r.accR.w;
     if (pc.table) {
-        bool ok = r.phase < (uint32_t)pc.rows;
-        if (ok) {
+        // A phase table in force is authoritative, like the spawn boxes are in the reference (SPH.cs:284-298 rewrites
+        // the static fields of every particle from its box each frame): a record packed before a live edit of its
+        // phase arrives with the old values and takes the current ones here.  A phase the table does not know keeps
+        // the record's own values and raises the flag (three-gather force kernel, 16-byte density candidates).
+        if (r.phase < (uint32_t)pc.rows) {
             const sph_phase ph = pc.table[r.phase];
-            ok = ph.mass == r.posM.w && ph.viscosity == r.velV.w && ph.restDensity == r.accR.w;
+            mass = ph.mass; visc = ph.viscosity; rho0 = ph.restDensity;
+        } else {
+            *pc.mismatch = 1;
         }
-        if (!ok) *pc.mismatch = 1;
     }
-    st.posM[k] = r.posM;
-    st.velV[k] = r.velV;
+    st.posM[k] = make_float4(r.posM.x, r.posM.y, r.posM.z, mass);
+    st.velV[k] = make_float4(r.velV.x, r.velV.y, r.velV.z, visc);
     st.acc[k] = make_float4(r.accR.x, r.accR.y, r.accR.z, 0.f);
     st.rhoP[k] = make_float2(r.density, r.pressure);
-    st.rho0[k] = r.accR.w;
+    st.rho0[k] = rho0;
     st.origId[k] = r.id;
 }
 

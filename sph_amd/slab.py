@@ -367,18 +367,19 @@ class SlabEngine:
         self.add_rows(0, np.asarray(aos, dtype=np.float32).reshape(-1, abi.PARTICLE_FLOATS))
 
     def set_phase_table(self, phases):
-        # slab records carry restDensity / viscosity / mass themselves; the table only tells the engine
-        # that mass and viscosity are per-phase constants (packed neighbour records of the force kernel).
-        # Live edits of a spawn box are not propagated to the particles in slab mode.
+        # The table is authoritative for the static properties (restDensity, viscosity, mass), like the spawn boxes are
+        # in the reference (SPH.cs:284-298): a live edit of a box reaches the local slots with apply_phase_table and the
+        # records that arrive later when they are stored.  Every rank gets the same table from its own host.SPH.
         self._phases = phases
-        if self._rows is None and hasattr(self.e, "set_phase_table"):
+        if self._rows is None:
             self.e.set_phase_table(phases)
 
     def set_phase_ids(self, ids):
-        pass
+        pass                                          # a slab keeps the phase per slot: it travels in the records
 
     def apply_phase_table(self):
-        pass
+        if self._rows is None:
+            self.e.apply_phase_table()
 
     # ---- grid: global resolution in, local slab out
     def resize_grid(self, rx, ry, rz, cap):

@@ -32,6 +32,12 @@ class _Shim:
         if kernel == abi.K_BUILD_GRID:
             self._p.after_build()
 
+    def set_phase_table(self, phases):
+        self._p.table = [tuple(float(v) for v in row[0:3]) for row in phases]      # (restDensity, viscosity, mass) per phase
+
+    def apply_phase_table(self):
+        self._p.apply_table()
+
     def read_counter(self, which=0):
         if which == abi.CTR_MAX_PLANE_SHIFT:
             return self._p.max_shift
@@ -46,6 +52,8 @@ class OraclePort:
         self.e = _Shim(self)
         self.device = torch.device("cpu")
         self.ids = np.zeros(0, np.uint32)          # global id of local particle k
+        self.phase = np.zeros(0, np.uint32)        # its phase (spawn box): travels in the records
+        self.table = None                          # the phase table in force (SlabEngine.set_phase_table)
         self.owned_mask = None                     # owned at the last grid build (None = all)
         self.carry_owned = None                    # after a rebuild: ids that were owned before it (received records are not)
         self.max_shift = 0
@@ -66,6 +74,7 @@ class OraclePort:
     def _set_local(self, recs):
         recs = recs[np.argsort(recs["id"], kind="stable")]
         self.ids = recs["id"].copy()
+        self.phase = recs["phase"].astype(np.uint32)
         n = recs.shape[0]
         self.ora.alloc_particles(max(n, 1))
         aos = abi.aos_from_records(recs) if n else np.zeros((1, 18), np.float32)
@@ -73,11 +82,29 @@ class OraclePort:
             aos[0, 0:3] = 1e9                      # a parked dummy; never owned
             aos[0, 9] = aos[0, 11] = 1.0
             self.ids = np.array([0xFFFFFFFF], np.uint32)
+            self.phase = np.zeros(1, np.uint32)
+        self._table_into(aos)                      # the table in force is authoritative (engine: store_record)
         self.ora.upload_particles(aos)
         self.ora._static_dirty = False
         self.owned_mask = None
         self.e.n = max(n, 1)
         return n
+
+    def _table_into(self, aos):
+        if self.table is None:
+            return
+        rows = np.asarray(self.table, dtype=np.float32)
+        known = (self.phase < rows.shape[0]) & (self.ids != 0xFFFFFFFF)
+        aos[known, 11:14] = rows[self.phase[known]]
+
+    def apply_table(self):
+        """A live edit of a spawn box: every local particle takes its phase's row (the grid and bins stay as they are)."""
+        if self.table is None or self.ids.size == 0:
+            return
+        aos = self.ora.download_particles()
+        self._table_into(aos)
+        self.ora.upload_particles(aos)
+        self.ora._static_dirty = False
 
     def upload_owned(self, records):
         self._set_local(np.array(records, copy=True))
@@ -92,7 +119,7 @@ class OraclePort:
 
     def _current(self):
         aos = self.ora.download_particles()
-        recs = abi.records_from_aos(aos, self.ids)
+        recs = abi.records_from_aos(aos, self.ids, self.phase)
         valid = self.ids != 0xFFFFFFFF
         if self.owned_mask is not None:
             owned = self.owned_mask & valid

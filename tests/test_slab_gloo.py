@@ -53,6 +53,27 @@ def moving_tank(engine, kind, n=1500):
     return sc
 
 
+class _BoxEdit:
+    """A live Inspector edit of the spawn boxes (SpawnBox.cs:11-17), as SPH.cs:284-298 picks it up on the next Update:
+    from frame 2 on phase 0 is more viscous, from frame 3 on phase 1 is denser and heavier."""
+
+    def __init__(self, sph, time):
+        self.sph, self.time = sph, time
+
+    def Update(self):
+        if self.time.frame == 2:
+            self.sph.spawnBoxes[0].viscosity = 0.25
+        if self.time.frame == 3:
+            self.sph.spawnBoxes[1].restDensity = 12.0
+            self.sph.spawnBoxes[1].particleMass = 0.25
+
+
+def edited_tank(engine, n=1500):
+    sc = small_tank(engine, n=n)
+    sc.movers.append(_BoxEdit(sc.sph, sc.time))
+    return sc
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -78,7 +99,7 @@ def _worker(rank, world, port, frames, out_dir, step_frame, ghost=8, rebalance_e
         oport.set_params_ref(p)
         orig(p)
     se.set_params = set_params
-    sc = moving_tank(se, motion) if motion else small_tank(se, sub_steps=sub_steps)
+    sc = edited_tank(se) if motion == "edit" else moving_tank(se, motion) if motion else small_tank(se, sub_steps=sub_steps)
     sc.sph.use_step_frame = step_frame
     sc.start()
     counts = []
@@ -281,3 +302,26 @@ def test_slab_ranges_cover_the_grid():
             r = slab.slab_ranges(rx, w)
             assert r[0][0] == 0 and r[-1][1] == rx
             assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+
+
+@pytest.mark.parametrize("world,overlap", [(2, False), (3, True)])
+def test_live_spawn_box_edit_reaches_every_slab(tmp_path, oracle_built, world, overlap):
+    """SPH.cs:284-298 rewrites restDensity / viscosity / mass of every particle from its spawn box each frame, so an
+    Inspector edit takes effect on the next Update.  In slab mode the edit travels as the phase table: local slots take
+    the new row at once, records packed BEFORE the edit (overlapped exchange: in flight) take it when they are stored.
+    Bit-identical to the single-domain run with the same edits, static fields included."""
+    frames = 7
+    from oracle.ora import Oracle
+    ref = Oracle()
+    sc = edited_tank(ref)
+    sc.run(frames)
+    want = ref.download_particles()
+    n = want.shape[0]
+    assert set(np.unique(want[:, 12]).tolist()) == {np.float32(0.25), np.float32(0.05)}      # the edit reached the single domain
+    assert set(np.unique(want[:, 13]).tolist()) == {np.float32(0.2), np.float32(0.25)}
+    mp.spawn(_worker, args=(world, _free_port(), frames, str(tmp_path), True, 8, 0, 1, overlap, "edit"), nprocs=world, join=True)
+    recs = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)])
+    assert np.load(tmp_path / "counts0.npy").tolist() == [n] * frames
+    got = abi.aos_from_records(recs[np.argsort(recs["id"])])
+    for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
+        assert np.array_equal(got[:, sl], want[:, sl]), "live edit: slab run differs from the single-domain run"

@@ -10,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from sph_amd import abi, slab
-from tests.test_slab_gloo import _free_port, moving_tank, small_tank
+from tests.test_slab_gloo import _free_port, edited_tank, moving_tank, small_tank
 
 pytestmark = pytest.mark.gpu
 
@@ -41,13 +41,15 @@ def _worker(rank, world, port, frames, out_dir, n, ghost, drop_phases, rebalance
     se = slab.SlabEngine(dport, comm, rank, world, ghost_planes=ghost, rebalance_every=rebalance_every,
                          max_cut_shift=4, rebalance_threshold=1.0, overlap=overlap, adaptive_ghost=adaptive)
     if drop_phases:
-        # records arrive without their spawn-box index: the second box's mass / viscosity / rest density
-        # then disagree with row 0 of the phase table, and the engine has to notice (PhaseCheck) and
-        # keep gathering mass and viscosity per particle
+        # records arrive with spawn-box indices the phase table does not know (200, 201 against a table of two rows):
+        # they keep the static properties they carry, and the engine has to notice (PhaseCheck) and keep gathering
+        # mass and viscosity per particle instead of looking them up by phase
         add = se.add_rows
-        se.add_rows = lambda first_id, rows, phase=0: add(first_id, rows, 0)
+        se.add_rows = lambda first_id, rows, phase=0: add(first_id, rows, 200 + phase)
     if tank in ("drift", "rock"):
         sc = moving_tank(se, tank, n=n)
+    elif tank == "edit":
+        sc = edited_tank(se, n=n)
     else:
         sc = (long_tank if tank == "long" else small_tank)(se, n=n, sub_steps=sub_steps)
     sc.sph.use_step_frame = True
@@ -280,3 +282,27 @@ def test_plane_counts_equal_download():
         eng.destroy()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,overlap", [(2, False), (3, True)])
+def test_live_spawn_box_edit_bitwise(tmp_path, world, overlap):
+    """A live edit of a spawn box (viscosity of phase 0 at frame 2; rest density and mass of phase 1 at frame 3:
+    tests/test_slab_gloo._BoxEdit) reaches every slab like it reaches one engine (SPH.cs:284-298): local slots through
+    sph_apply_phase_table, records that were packed before the edit when they are stored.  Mass differs between the
+    phases afterwards, so the run also leaves the uniform-mass paths mid-way.  Bit-identical, static fields included."""
+    frames, n = 8, 3000
+    eng = abi.Engine(0)
+    sc = edited_tank(eng, n=n)
+    sc.sph.use_step_frame = True
+    sc.run(frames)
+    want = eng.download_particles()
+    eng.destroy()
+    n = want.shape[0]
+    assert set(np.unique(want[:, 13]).tolist()) == {np.float32(0.2), np.float32(0.25)}
+    mp.spawn(_worker, args=(world, _free_port(), frames, str(tmp_path), n, 8, False, 0, 1, overlap, "edit"), nprocs=world, join=True)
+    recs = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)])
+    meta = np.load(tmp_path / "meta0.npy")
+    assert meta[:-1].tolist() == [n] * frames and meta[-1] == 0, meta
+    got = abi.aos_from_records(recs[np.argsort(recs["id"])])
+    for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
+        assert np.array_equal(got[:, sl], want[:, sl]), f"live edit: {world} slabs differ from one engine"
