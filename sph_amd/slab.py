@@ -561,6 +561,14 @@ class SlabEngine:
         self.n = int(ids.shape[0])
         self.e.n = self.n
         self._primed = False
+        self._cuts_next = None
+        if self.adaptive and (self.wk != [self.ghost] * 2 or self.ws != [self.ghost] * 2):
+            # the measured shifts describe the state that was replaced: back to the full ghost width
+            rx, ry, rz, cap = self.grid
+            self.wk, self.ws, self._shifts = [self.ghost] * 2, [self.ghost] * 2, []
+            self.keep = self._keep_range()
+            self.port.reconfigure(rx, self.keep[0], self.keep[1] - self.keep[0], ry, rz, cap, self.own[0], self.own[1])
+        self._shifts = []
 
     def set_delta_time(self, dt):
         self.e.set_delta_time(dt)
@@ -666,6 +674,27 @@ class SlabEngine:
 
     def owned_records(self):
         return self.port.download_owned()
+
+    def download_particles(self, root=None):
+        """GetParticleBuffer of a slab run (SPH.cs:105-110): the 72-byte records of ALL particles in global id order,
+        owned particles gathered from every rank -- on every rank (root None) or on `root` only (the others get None).
+        Colours come from the phase table (a slab does not carry them).  Collective."""
+        recs = self.owned_records()
+        if self.world > 1:
+            parts = [recs if (root is None or r == root) else recs[:0] for r in range(self.world)]
+            recs = self.comm.all_to_all_records(parts)
+            if root is not None and self.rank != root:
+                return None
+        if recs.shape[0] != self.n_global or not np.array_equal(np.sort(recs["id"]), np.arange(self.n_global, dtype=np.uint32)):
+            raise RuntimeError(f"gathered {recs.shape[0]} records for {self.n_global} particles: the slabs do not partition the ids")
+        recs = recs[np.argsort(recs["id"], kind="stable")]
+        aos = abi.aos_from_records(recs)
+        rows = getattr(self, "_phases", None)
+        if rows:
+            colours = np.asarray([np.asarray(r[3], dtype=np.float32).reshape(4) for r in rows], dtype=np.float32)
+            known = recs["phase"] < len(rows)
+            aos[known, 14:18] = colours[recs["phase"][known]]
+        return aos
 
     def count_global(self):
         return self.comm.allreduce_sum(int(self.owned_records().shape[0]))

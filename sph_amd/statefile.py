@@ -12,7 +12,10 @@ record as the file format, so a Unity build could `SetData` the file unchanged:
                   the grid is state, not a function of the cube), the Inspector fields and spawn boxes
 
 save_state / load_state resume a run bit for bit (tests/test_statefile_gpu.py): the engine's results
-depend on the (cell, id) order only, never on the slot order the previous frames left behind.
+depend on the (cell, id) order only, never on the slot order the previous frames left behind.  The same
+file serves slab-decomposed runs (sph_amd.slab): rank 0 writes it from the gathered owned particles, every
+rank loads it and keeps its owned planes; slab runs are bit-identical to one-GPU runs, so a file moves
+between any numbers of GPUs (tests/test_slab_gpu.py, tests/test_slab_gloo.py: test_checkpoints_*).
 
 write_ply / splat_png are for visual regression against the reference's screenshots (readme_files/):
 a binary PLY point cloud any viewer opens, and a small orthographic point splat with no dependencies.
@@ -39,16 +42,34 @@ def _l(v):
     return [float(x) for x in np.asarray(v).reshape(-1)]
 
 
+def _phase_by_id(sph) -> np.ndarray:
+    """particleSpawnBoxIndices (SPH.cs:75, 276); a slab run does not materialise it: ids are dealt box by box."""
+    if sph.particleSpawnBoxIndices is not None:
+        return np.ascontiguousarray(sph.particleSpawnBoxIndices, dtype=np.uint8)
+    counts = [sb.particleCount for sb in sph.spawnBoxes]
+    if sum(counts) == sph.particleCount and len(counts) <= 256:
+        return np.repeat(np.arange(len(counts), dtype=np.uint8), counts)
+    return np.zeros(sph.particleCount, dtype=np.uint8)
+
+
 def save_state(scene, prefix: str) -> dict:
-    """Write <prefix>.bin/.phase/.json for a started host.Scene (single-GPU engine).  Synchronises."""
+    """Write <prefix>.bin/.phase/.json for a started host.Scene.  Synchronises.  On a slab-decomposed run
+    (sph_amd.slab.SlabEngine) the call is collective: the owned particles of all ranks are gathered on rank 0, which
+    writes the SAME file a one-GPU run writes at that frame (slab runs are bit-identical to it), so a run can be resumed
+    on any number of GPUs; the other ranks return None."""
     sph = scene.sph
-    aos = np.ascontiguousarray(sph.GetParticleBuffer(), dtype="<f4")
+    e = sph.engine
+    if hasattr(e, "resync"):                       # slab run
+        aos = e.download_particles(root=0)
+        if aos is None:
+            return None
+    else:
+        aos = sph.GetParticleBuffer()
+    aos = np.ascontiguousarray(aos, dtype="<f4")
     if aos.shape != (sph.particleCount, abi.PARTICLE_FLOATS):
         raise ValueError(f"particle buffer has shape {aos.shape}")
     aos.tofile(prefix + ".bin")
-    phase = sph.particleSpawnBoxIndices
-    if phase is None:
-        phase = np.zeros(sph.particleCount, dtype=np.uint8)
+    phase = _phase_by_id(sph)
     np.ascontiguousarray(phase, dtype=np.uint8).tofile(prefix + ".phase")
     meta = {
         "format": FORMAT, "version": VERSION, "record_bytes": abi.PARTICLE_BYTES, "particleCount": int(sph.particleCount),
@@ -120,6 +141,13 @@ def load_state(scene, prefix: str) -> dict:
         sph.boundaryCube.rotation = np.asarray(cube["rotation"], dtype=np.float32)
         sph.lastBoundaryCubePosition = np.asarray(cube["lastPosition"], dtype=np.float32)
         sph.lastBoundaryCubeRotation = np.asarray(cube["lastRotation"], dtype=np.float32)
+    if hasattr(e, "resync"):
+        # slab run: every rank reads the file; a grid that differs from the one the run started with re-partitions the
+        # slabs (SetComputeParams -> SlabEngine.set_params), then every rank keeps the particles of its owned planes
+        sph.SetComputeParams()
+        e.set_phase_table(sph._phase_rows())
+        e.resync(aos, phase)
+        return meta
     e.upload_particles(aos)
     sph.particleSpawnBoxIndices = phase.copy()
     e.set_phase_table(sph._phase_rows())

@@ -325,3 +325,62 @@ def test_live_spawn_box_edit_reaches_every_slab(tmp_path, oracle_built, world, o
     got = abi.aos_from_records(recs[np.argsort(recs["id"])])
     for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
         assert np.array_equal(got[:, sl], want[:, sl]), "live edit: slab run differs from the single-domain run"
+
+
+# ---------------------------------------------------------------------------------------------- checkpoints
+def _ckpt_worker(rank, world, port, out_dir, mode, overlap):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.ora import Oracle
+    from sph_amd import statefile
+    from tests.slab_oracle_port import OraclePort
+    oport = OraclePort(Oracle())
+    se = slab.SlabEngine(oport, slab.NeighbourComm(rank, world, torch.device("cpu"), backend="gloo"), rank, world,
+                         ghost_planes=8, overlap=overlap)
+    orig = se.set_params
+
+    def set_params(p):
+        oport.set_params_ref(p)
+        orig(p)
+    se.set_params = set_params
+    sc = small_tank(se)
+    sc.sph.use_step_frame = True
+    sc.start()
+    if mode == "save":
+        sc.run(4)
+        meta = statefile.save_state(sc, os.path.join(out_dir, "slab"))
+        assert (meta is not None) == (rank == 0)
+    else:
+        sc.run(2)                                    # some other state first: the load must replace all of it
+        statefile.load_state(sc, os.path.join(out_dir, "single"))
+    sc.run(3)
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"), se.owned_records())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,overlap", [(2, False), (3, True)])
+def test_checkpoints_move_between_one_domain_and_slabs(tmp_path, oracle_built, world, overlap):
+    """sph_amd.statefile on a slab run: rank 0 writes, from the gathered owned particles, byte for byte the file the
+    single-domain run writes at that frame; and a slab run that loads the single-domain file continues it bit for bit
+    (every rank keeps the particles of its owned planes, ghosts come with the next exchange)."""
+    from oracle.ora import Oracle
+    from sph_amd import statefile
+    ref = Oracle()
+    sc = small_tank(ref)
+    sc.run(4)
+    single = statefile.save_state(sc, str(tmp_path / "single"))
+    sc.run(3)
+    want = ref.download_particles()
+    for mode in ("save", "load"):
+        mp.spawn(_ckpt_worker, args=(world, _free_port(), str(tmp_path), mode, overlap), nprocs=world, join=True)
+        recs = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)])
+        got = abi.aos_from_records(recs[np.argsort(recs["id"])])
+        for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
+            assert np.array_equal(got[:, sl], want[:, sl]), f"{mode}: the slab run does not continue the single-domain run"
+        if mode == "save":
+            for ext in (".bin", ".phase"):
+                assert open(tmp_path / ("slab" + ext), "rb").read() == open(tmp_path / ("single" + ext), "rb").read(), ext
+            import json
+            slabmeta = json.load(open(tmp_path / "slab.json"))
+            assert slabmeta == json.loads(json.dumps(single))

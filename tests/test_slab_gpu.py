@@ -306,3 +306,57 @@ def test_live_spawn_box_edit_bitwise(tmp_path, world, overlap):
     got = abi.aos_from_records(recs[np.argsort(recs["id"])])
     for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
         assert np.array_equal(got[:, sl], want[:, sl]), f"live edit: {world} slabs differ from one engine"
+
+
+# ---------------------------------------------------------------------------------------------- checkpoints
+def _ckpt_worker(rank, world, port, out_dir, mode, n, overlap):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sph_amd import statefile
+    eng = abi.Engine(0)
+    se = slab.SlabEngine(slab.DevicePort(eng, 0, msg_capacity=n), slab.NeighbourComm(rank, world, torch.device("cuda", 0), backend="gloo"),
+                         rank, world, ghost_planes=8, overlap=overlap, adaptive_ghost=True)
+    sc = small_tank(se, n=n)
+    sc.sph.use_step_frame = True
+    sc.start()
+    if mode == "save":
+        sc.run(4)
+        meta = statefile.save_state(sc, os.path.join(out_dir, "slab"))
+        assert (meta is not None) == (rank == 0)
+    else:
+        sc.run(2)
+        statefile.load_state(sc, os.path.join(out_dir, "single"))
+    sc.run(4)
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"), se.owned_records())
+    np.save(os.path.join(out_dir, f"meta{rank}.npy"), np.array([se.halo_violations + se.band_misses]))
+    eng.destroy()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,overlap", [(2, True), (3, False)])
+def test_checkpoints_move_between_one_gpu_and_slabs(tmp_path, world, overlap):
+    """A raw-state file (sph_amd.statefile) written by one engine is continued bit for bit by 2 / 3 slabs, and the file
+    the slabs write (rank 0, from the gathered owned particles) is byte for byte the one-engine file of that frame."""
+    import json
+    from sph_amd import statefile
+    n = 3000
+    eng = abi.Engine(0)
+    sc = small_tank(eng, n=n)
+    sc.sph.use_step_frame = True
+    sc.run(4)
+    single = statefile.save_state(sc, str(tmp_path / "single"))
+    sc.run(4)
+    want = eng.download_particles()
+    eng.destroy()
+    for mode in ("save", "load"):
+        mp.spawn(_ckpt_worker, args=(world, _free_port(), str(tmp_path), mode, want.shape[0], overlap), nprocs=world, join=True)
+        recs = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)])
+        assert sum(int(np.load(tmp_path / f"meta{r}.npy")[0]) for r in range(world)) == 0
+        got = abi.aos_from_records(recs[np.argsort(recs["id"])])
+        for sl in (slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 14)):
+            assert np.array_equal(got[:, sl], want[:, sl]), f"{mode}: {world} slabs do not continue the one-engine run"
+        if mode == "save":
+            for ext in (".bin", ".phase"):
+                assert open(tmp_path / ("slab" + ext), "rb").read() == open(tmp_path / ("single" + ext), "rb").read(), ext
+            assert json.load(open(tmp_path / "slab.json")) == json.loads(json.dumps(single))
