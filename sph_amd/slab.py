@@ -364,6 +364,8 @@ class SlabEngine:
         self._rows.append(abi.records_from_aos(rows[m], ids, phase))
 
     def upload_particles(self, aos):
+        if self._rows is None:
+            raise RuntimeError("the particles are distributed already: replace the state with resync(aos, phase_of_id)")
         self.add_rows(0, np.asarray(aos, dtype=np.float32).reshape(-1, abi.PARTICLE_FLOATS))
 
     def set_phase_table(self, phases):
