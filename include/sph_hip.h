@@ -143,7 +143,11 @@ typedef struct sph_timings {
 } sph_timings;
 
 /* ---- lifetime ------------------------------------------------------------------------ */
-/* Replaces the implicit device of the Unity player.  device_id = HIP ordinal. */
+/* Replaces the implicit device of the Unity player.  device_id = HIP ordinal.
+ * One context drives ONE device: more GPUs are more contexts, one per process and GPU (the sph_slab_* entry points
+ * below make a context one slab of a decomposed run, the host exchanges the face messages -- sph_amd/slab.py over
+ * RCCL).  A context spanning several devices in one process, as a (ctx**, const int* device_ids, int n) signature
+ * would suggest, does not exist on purpose: the messages between slabs belong to the host's communicator. */
 int  sph_create(sph_ctx** out, int device_id);
 /* SPH.OnDestroy (SPH.cs:235-241): ComputeBuffer.Release x4. */
 int  sph_destroy(sph_ctx* ctx);
