@@ -434,6 +434,11 @@ class SlabEngine:
         faces = [widths[k] for k in (0, 1) if (self.rank > 0 if k == 0 else self.rank < self.world - 1)]
         if faces and 2 * self.sub_steps * (1 + shift) > min(faces):
             self.halo_violations += 1
+        # A particle that crosses a WHOLE neighbouring slab in one frame would reach a rank it is never sent to (messages
+        # go to the two face neighbours only; SURVEY 8e's all-to-all fallback is not built): stop rather than lose it.
+        if self.world > 1 and self.cuts is not None and shift >= min(b - a for a, b in zip(self.cuts[:-1], self.cuts[1:])):
+            raise RuntimeError(f"a particle moved {shift} cell planes in one frame, more than the narrowest slab is wide: "
+                               f"the run has diverged or the slabs are too narrow for it")
 
     def _adapt(self, in_flight: bool):
         """New face widths from this rank's need and the neighbours' (comm.peer_need, same frame): both ranks of a face
