@@ -80,6 +80,12 @@ struct sph_ctx {
     bool packedValid = false;         // nbrA / nbrB match the mask (phase table of <= 4 rows in force)
     bool maskValid = false;           // hitMask matches the current positions and grid
     bool useHitMask = true;           // SPH_HIP_HITMASK=0 turns the hit path off
+    // SPH_HIP_ROW_SLACK: how many cell rows a lane of the force kernel's hit walk may run ahead of its wave's slowest
+    // lane (8 = ungated).  Measured at 1 M particles (scripts/gpu_row_slack*.sh), force kernel in the driver's window /
+    // at the defaults: 0 -> 0.236 / 0.152 ms, 1 -> 0.190 / 0.127, 2 -> 0.181 / 0.121, 3 -> 0.174 / 0.116, 4 -> 0.172 / 0.114,
+    // 8 -> 0.1745 / 0.116.  Walking the rows in step does make a gather touch fewer lines, but the lanes of a wave have
+    // similar hit counts per row and stay roughly in step by themselves; a tight gate only adds idle lanes.
+    int rowSlack = 4;
     int xcdRunOverride = 0;           // SPH_HIP_XCD_RUN=<n> pins the XCD run length (experiments)
     bool debug = false;               // SPH_HIP_DEBUG=1: report on stderr which force kernel runs
     int lastForceVariant = -1;
@@ -581,7 +587,7 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
 #define FORCE_HITS(MODE_)                                                                                                     \
     LAUNCH_T(c, f0, f1, k_force_xsph_hits<MODE_>, dim3(nb), c->dp, (const float4*)s.posM, (const float4*)s.velV,             \
              (const float2*)s.rhoP, s.acc, velOut, (const int*)c->cellCum, (const int*)c->counters, (const uint32_t*)c->hitMask, \
-             c->capacity, (const float4*)c->nbrA, (const float4*)c->nbrB, ph, fused ? 1 : 0)
+             c->capacity, (const float4*)c->nbrA, (const float4*)c->nbrB, ph, fused ? 1 : 0, c->rowSlack)
             if (mode == 2) FORCE_HITS(2);
             else if (mode == 1) FORCE_HITS(1);
             else if (mode == 0) FORCE_HITS(0);
@@ -648,6 +654,7 @@ int sph_create(sph_ctx** out, int device_id) {
     if (!c) return SPH_E_NOMEM;
     c->device = device_id;
     if (const char* tl = getenv("SPH_HIP_TIMING")) c->timingLevel = atoi(tl);
+    if (const char* rs = getenv("SPH_HIP_ROW_SLACK")) c->rowSlack = std::min(std::max(atoi(rs), 0), 8);
     if (const char* ef = getenv("SPH_HIP_EVENT_FENCE")) c->eventFlags = atoi(ef) ? hipEventDefault : hipEventDisableSystemFence;
     if (const char* ts = getenv("SPH_HIP_TIMING_STRIDE")) c->timingStride = std::max(1, atoi(ts));
     if (const char* hm = getenv("SPH_HIP_HITMASK")) c->useHitMask = atoi(hm) != 0;

@@ -517,7 +517,7 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
                                                             const uint32_t* __restrict__ hitMask, int maskStride,
                                                             const float4* __restrict__ nbrA,
                                                             const float4* __restrict__ nbrB, PhaseConsts ph,
-                                                            int zeroDeadAcc) {
+                                                            int zeroDeadAcc, int rowSlack) {
     // one buffer, two uses: (a) per lane the non-empty mask words and the slot of their bit 0,
     // (b) the scan path's hit FIFO.  Every thread only touches its own column.
     static_assert(kMaskWords + 9 >= kHitQueue, "the FIFO lives in the word list's LDS");
@@ -600,16 +600,27 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
             }
         }
         constexpr bool packed = MODE != 0;
-        // 3) walk the set bits: visiting order, one add per hit to find its slot
-        int li = 0, base = 0;
+        // 3) walk the set bits: visiting order, one add per hit to find its slot.
+        //    The lanes of a wave walk their rows TOGETHER: a lane may start a word of row r only while
+        //    r <= (the row the slowest lane is in) + rowSlack.  A lane's own sequence is unchanged (same hits, same
+        //    order, same sums); what changes is WHERE the 64 gathers of one instruction point: into the windows of
+        //    1 + rowSlack cell rows instead of all nine, i.e. ~12 lines per row instead of ~45, and a wave-wide gather
+        //    costs the texture addresser ~0.8 clk per distinct line (scripts/experiments/gather_rate.hip).  The price
+        //    is idle lanes while a row's busiest lane finishes; rowSlack >= 8 is the ungated walk.  Measured: the lanes
+        //    of a wave have similar hit counts per row and stay nearly in step by themselves -- a loose gate (4 rows,
+        //    the host's default) is worth ~1 %, a tight one costs up to 35 % (libsph_hip.hip, rowSlack).
+        int li = 0, base = 0, rowOfW = 0;
         uint32_t w = 0;
+        int nxt = cnt > 0 ? (int)codeOf[0][tid] : (9 << 3);      // code of the next word to start; row 9 = none left
+        int curRow = 0;                                          // wave-uniform: no lane has hits left in a row below it
         const int nLast = P.n - 1;
-        auto pop = [&](int& j) -> bool {
-            if (w == 0 && li < cnt) {
+        auto pop = [&](int& j, int limit) -> bool {
+            if (w == 0 && (nxt >> 3) <= limit) {
                 w = (uint32_t)wordOf[li][tid];
-                const int code = codeOf[li][tid];
-                base = rowA[code >> 3][tid] + ((code & 7) << 5);     // slot of the word's bit 0
+                rowOfW = nxt >> 3;
+                base = rowA[rowOfW][tid] + ((nxt & 7) << 5);     // slot of the word's bit 0
                 li++;
+                nxt = li < cnt ? (int)codeOf[li][tid] : (9 << 3);
             }
             if (w == 0) { j = me.sl; return false; }
             j = min(base + __builtin_ctz(w), nLast);     // the min only guards against a stale mask
@@ -624,9 +635,12 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
             bool h0, h1;
         };
         auto fetch = [&](Stage& S) {
+            // the row the slowest lane is in (a lane between words counts with the word it starts next)
+            while (curRow < 9 && !__any((w != 0 ? rowOfW : (nxt >> 3)) <= curRow)) curRow++;
+            const int limit = min(curRow + rowSlack, 8);
             int j0, j1;
-            S.h0 = pop(j0);
-            S.h1 = pop(j1);
+            S.h0 = pop(j0, limit);
+            S.h1 = pop(j1, limit);
             if (packed) {
                 S.q0 = nbrA[j0]; S.u0 = nbrB[j0];
                 S.q1 = nbrA[j1]; S.u1 = nbrB[j1];
