@@ -796,7 +796,13 @@ def bench_main(args, rank, local_rank, world):
     misses = comm.allreduce_sum(se.band_misses)
     overflow = comm.allreduce_sum(eng.read_counter(abi.CTR_BIN_OVERFLOW))
     force_ms = comm.allreduce_max(tm["force_ms"])
-    n_owned_here = int(se.owned_records().shape[0]) if os.environ.get("SPH_BENCH_GHOST_RATIO", "1") != "0" else -1
+    # after the timed region: every id owned exactly once over all ranks (count and id sum), and the ghost share
+    n_owned_here, conserved = -1, None
+    if os.environ.get("SPH_BENCH_GHOST_RATIO", "1") != "0":
+        owned_ids = se.owned_records()["id"].astype(np.int64)
+        n_owned_here = int(owned_ids.shape[0])
+        totals = comm.allreduce_sum_array(np.array([n_owned_here, int(owned_ids.sum())], dtype=np.int64))
+        conserved = bool(totals[0] == n_total and totals[1] == n_total * (n_total - 1) // 2)
     ghost_ratio = comm.allreduce_max((se.n_built - n_owned_here) / max(n_owned_here, 1)) if n_owned_here >= 0 else None
     faces = [se.wk[k] for k in (0, 1) if (rank > 0 if k == 0 else rank < world - 1)] or [ghost]
     widths_min = -comm.allreduce_max(-float(min(faces)))
@@ -852,7 +858,7 @@ def bench_main(args, rank, local_rank, world):
                        "particles": n_total, "sub_steps": sub, "parallelism": f"slab{world}",
                        "world_size": dist.get_world_size(), "backend": dist.get_backend(), "rehearsal": rehearsal,
                        "self_launched": os.environ.get("SPH_BENCH_SELF_LAUNCHED") == "1",
-                       "halo_violations": viol, "bin_overflow_cells": overflow,
+                       "halo_violations": viol, "bin_overflow_cells": overflow, "every_id_owned_once": conserved,
                        "adaptive_ghost": se.adaptive, "ghost_planes_at_end": [int(widths_min), int(widths_max)],
                        "ghost_to_owned_particles_worst_rank": ghost_ratio,
                        "rebalance_every": se.rebalance_every, "recuts": se.recuts,
