@@ -37,7 +37,6 @@ for f in range(1, 51):
     over = (nwords > 24) | big
     order = ids.astype(np.int64)                    # slot -> id
     ov = over[order]
-    nw_slot = nwords[order]
     waves = ov[: len(ov) // 64 * 64].reshape(-1, 64).any(axis=1)
     print(f"frame {f}: candidates/particle {cand.mean():.0f}, mask words mean {nwords.mean():.1f} p99 {np.percentile(nwords, 99):.0f} max {nwords.max()}, "
           f"particles over 24 words {over.mean() * 100:.2f} %, waves on the scan path {waves.mean() * 100:.2f} %", flush=True)

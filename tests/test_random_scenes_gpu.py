@@ -103,7 +103,6 @@ def test_random_scene_lockstep(seed):
     se.start()
     so.start()
     frames = 4
-    seen_overflow = 0
     probe = sp = None
     if d["subSteps"] > 1:                                   # the oracle again, on inputs one ulp off: the frame's conditioning
         probe = Oracle()
@@ -139,7 +138,6 @@ def test_random_scene_lockstep(seed):
             assert_fields_close(got, want, TOL, what)
         ctr = [ora.read_counter(k) for k in range(3)]
         assert [eng.read_counter(k) for k in range(3)] == ctr, what + "counters"
-        seen_overflow += ctr[1]
     eng.destroy()
     ora.destroy()
     if probe:
