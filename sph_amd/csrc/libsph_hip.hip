@@ -51,8 +51,11 @@ struct sph_ctx {
     int n = 0;            // particle count
     int capacity = 0;     // allocated particle capacity
     StateSet set[2] = {};
-    int cur = 0;          // set[cur] holds posM/acc/rhoP/rho0/origId; velCur picks velV
+    int cur = 0;          // set[cur] holds acc/rhoP/rho0/origId; velCur picks velV, posCur picks posM
     int velCur = 0;
+    int posCur = 0;       // (the force kernel with the fused tail writes the new positions into the other buffer)
+    bool fuseTailOk = true;   // SPH_HIP_FUSE_TAIL=0: sph_step_frame keeps the separate tail pass (A/B)
+    bool tailFusedLast = false;   // the last CS_ForceXSPH launch applied the frame's tail itself
     float4* color = nullptr;       // by id
     uint8_t* phaseOfId = nullptr;  // by id
     bool havePhaseIds = false;
@@ -359,7 +362,8 @@ int harvestSlot(sph_ctx* c, int slot) {
     if (!rc) rc = span(E_DENS0, E_DENS1, 2);
     if (!rc) rc = span(E_FORCE0, E_FORCE1, 3);
     if (!rc) rc = span(E_TAIL0, E_TAIL1, 4);                  // fused tail: full step + boundary (+ damping)
-    if (!rc) rc = span(E_GRID0, E_TAIL1, 7);                  // whole frame, first launch to last
+    // whole frame, first launch to last (the force kernel is the last one when it applied the tail itself)
+    if (!rc) rc = span(E_GRID0, (rec & (1u << E_TAIL1)) ? E_TAIL1 : E_FORCE1, 7);
     if (rc) return rc;
     c->framesTimed++;
     return SPH_OK;
@@ -368,6 +372,7 @@ int harvestSlot(sph_ctx* c, int slot) {
 StateSet curSet(sph_ctx* c) {
     StateSet s = c->set[c->cur];
     s.velV = c->set[c->velCur].velV;
+    s.posM = c->set[c->posCur].posM;
     return s;
 }
 
@@ -389,8 +394,7 @@ int applyPhaseTable(sph_ctx* c) {
     }
     if (c->phaseTable.empty() || !c->havePhaseIds) { c->staticDirty = false; return SPH_OK; }
     hipLaunchKernelGGL(k_apply_phase_table, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->n,
-                       StateSet{c->set[c->cur].posM, c->set[c->velCur].velV, c->set[c->cur].acc,
-                                c->set[c->cur].rhoP, c->set[c->cur].rho0, c->set[c->cur].origId},
+                       curSet(c),
                        c->color, c->phaseOfId, c->phaseTableDev);
     CHECK_LAUNCH(c);
     c->staticDirty = false;
@@ -462,12 +466,13 @@ int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
         c->slabMismatchClean = c->hostInts[2] == 0;   // every record of this frame has been checked by now (same stream)
         c->n = nNew;
         c->dp.n = nNew;
-        if (nNew == 0) { c->cur = 1 - c->cur; c->velCur = 1 - c->velCur; c->gridValid = true; return SPH_OK; }
+        if (nNew == 0) { c->cur = 1 - c->cur; c->velCur = 1 - c->velCur; c->posCur = 1 - c->posCur; c->gridValid = true; return SPH_OK; }
     }
     const int nbNew = blocksFor(nNew);
     StateSet dst = c->set[1 - c->cur];
     // velocities of the new order go to the set that does NOT hold the current ones
     dst.velV = c->set[1 - c->velCur].velV;
+    dst.posM = c->set[1 - c->posCur].posM;
     if (fuseHalfStep)   // sph_step_frame: rank + reorder + first CS_VvHalfStep in one pass
         LAUNCH_T(c, -1, E_GRID1, k_rank_move<true>, dim3(nbNew), c->sortedKeys, perm, c->sid, nNew, c->cap, c->dp.dt, c->cellCum, src,
                  dst, c->counters, c->pos3);
@@ -478,6 +483,7 @@ int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
     c->pos3Valid = fuseHalfStep;
     c->cur = 1 - c->cur;
     c->velCur = 1 - c->velCur;
+    c->posCur = 1 - c->posCur;
     c->gridValid = true;
     return SPH_OK;
 }
@@ -584,10 +590,20 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
                 v[k] = c->phaseTable[k].viscosity;
             }
             const PhaseConsts ph{m[0], m[1], m[2], m[3], v[0], v[1], v[2], v[3]};
-#define FORCE_HITS(MODE_)                                                                                                     \
-    LAUNCH_T(c, f0, f1, k_force_xsph_hits<MODE_>, dim3(nb), c->dp, (const float4*)s.posM, (const float4*)s.velV,             \
+            // one GPU, sph_step_frame, hit path: the force kernel applies the frame's tail itself (TailArgs); the new
+            // positions go to the other position buffer
+            const bool fuseTail = fused && !c->slab && mode >= 0 && c->fuseTailOk && wgPhase < 0;
+            c->tailFusedLast = fuseTail;
+            TailArgs tail{nullptr, 0, nullptr, nullptr};
+            if (fuseTail) {
+                if (int rcFold = foldCollisions(c)) return rcFold;
+                tail = TailArgs{c->set[1 - c->posCur].posM, lastSub ? 1 : 0, c->blockCollide, c->counters};
+            }
+#define FORCE_HITS_T(MODE_, TAIL_)                                                                                            \
+    LAUNCH_T(c, f0, f1, (k_force_xsph_hits<MODE_, TAIL_>), dim3(nb), c->dp, (const float4*)s.posM, (const float4*)s.velV,     \
              (const float2*)s.rhoP, s.acc, velOut, (const int*)c->cellCum, (const int*)c->counters, (const uint32_t*)c->hitMask, \
-             c->capacity, (const float4*)c->nbrA, (const float4*)c->nbrB, ph, fused ? 1 : 0, c->rowSlack)
+             c->capacity, (const float4*)c->nbrA, (const float4*)c->nbrB, ph, fused ? 1 : 0, c->rowSlack, tail)
+#define FORCE_HITS(MODE_) do { if (fuseTail) FORCE_HITS_T(MODE_, true); else FORCE_HITS_T(MODE_, false); } while (0)
             if (mode == 2) FORCE_HITS(2);
             else if (mode == 1) FORCE_HITS(1);
             else if (mode == 0) FORCE_HITS(0);
@@ -595,7 +611,14 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
                 LAUNCH_T(c, f0, f1, k_force_xsph_rows, dim3(nb), c->dp, (const float4*)s.posM, (const float4*)s.velV,
                          (const float2*)s.rhoP, s.acc, velOut, (const int*)c->cellCum, (const int*)c->counters, fused ? 1 : 0);
 #undef FORCE_HITS
+#undef FORCE_HITS_T
             if (wgPhase != 1) c->velCur = 1 - c->velCur;
+            if (fuseTail) {   // what the separate tail pass leaves behind
+                c->posCur = 1 - c->posCur;
+                c->collideFoldBlocks = nb;
+                c->maskValid = false;
+                c->pos3Valid = false;
+            }
             break;
         }
         case SPH_K_VV_HALF_STEP:
@@ -662,6 +685,7 @@ int sph_create(sph_ctx** out, int device_id) {
     if (const char* dbg = getenv("SPH_HIP_DEBUG")) c->debug = atoi(dbg) != 0;
     if (const char* um = getenv("SPH_HIP_UNIFORM_MASS")) c->uniformMassOk = atoi(um) != 0;
     if (const char* up = getenv("SPH_HIP_UNIFORM_PHASE")) c->uniformPhaseOk = atoi(up) != 0;
+    if (const char* ft = getenv("SPH_HIP_FUSE_TAIL")) c->fuseTailOk = atoi(ft) != 0;
     if (const char* gf = getenv("SPH_HIP_GHOST_FORCE")) c->skipGhostForce = atoi(gf) == 0;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
@@ -750,7 +774,7 @@ int sph_alloc_particles(sph_ctx* c, int n) {
     int rc = allocCapacity(c, n);
     if (rc) return rc;
     c->n = n;
-    c->cur = 0; c->velCur = 0;
+    c->cur = 0; c->velCur = 0; c->posCur = 0;
     c->gridValid = false; c->maskValid = false;
     c->havePhaseIds = false;
     // a fresh ComputeBuffer is zero-filled; give ids so download before upload is well defined
@@ -772,7 +796,7 @@ int sph_upload_particles(sph_ctx* c, const void* aos72, int n) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // previous use of the staging buffers
     memcpy(c->pinned, aos72, bytes);
     HIP_TRY(c, hipMemcpyAsync(c->aosStage, c->pinned, bytes, hipMemcpyHostToDevice, c->stream));
-    c->cur = 0; c->velCur = 0;
+    c->cur = 0; c->velCur = 0; c->posCur = 0;
     hipLaunchKernelGGL(k_import_aos, dim3(blocksFor(n)), dim3(kBlock), 0, c->stream, n, c->aosStage, c->set[0], c->color);
     CHECK_LAUNCH(c);
     c->gridValid = false; c->maskValid = false;
@@ -975,7 +999,7 @@ int sph_step_frame(sph_ctx* c, int sub_steps, float time_step) {
         if ((rc = dispatchKernel(c, SPH_K_DENSITY_PRESSURE))) return rc;
         if (last && split) {
             if ((rc = dispatchKernel(c, SPH_K_FORCE_XSPH, true, last, 1))) return rc;       // band workgroups
-            StateSet st = c->set[c->cur];
+            StateSet st = curSet(c);
             st.velV = c->set[1 - c->velCur].velV;                                           // what the force launch wrote
             hipLaunchKernelGGL(k_slab_pack_final, dim3((c->n + kBlock * kKeepItems - 1) / (kBlock * kKeepItems)), dim3(kBlock), 0,
                                c->stream, c->dp, st, c->ownedRef, (const uint8_t*)c->wgBand, 1, ap.leftBelow, ap.rightFrom,
@@ -993,7 +1017,7 @@ int sph_step_frame(sph_ctx* c, int sub_steps, float time_step) {
             c->bandSendLo = ap.leftBelow; c->bandSendHi = ap.rightFrom;
         }
         if ((rc = dispatchKernel(c, SPH_K_FORCE_XSPH, true, last, last && split ? 0 : -1))) return rc;
-        if ((rc = dispatchKernel(c, SPH_K_VV_FULL_STEP, true, last))) return rc;
+        if (!c->tailFusedLast && (rc = dispatchKernel(c, SPH_K_VV_FULL_STEP, true, last))) return rc;
     }
     if (timed) {
         c->slotPending[slot] = true;
@@ -1183,7 +1207,7 @@ int sph_slab_reserve(sph_ctx* c, int capacity) {
         if (c->n > 0) return fail(c, SPH_E_STATE, "sph_slab_reserve cannot grow a populated slab (reserve before upload)");
         int rc = allocCapacity(c, capacity);
         if (rc) return rc;
-        c->n = 0; c->cur = 0; c->velCur = 0; c->gridValid = false; c->maskValid = false;
+        c->n = 0; c->cur = 0; c->velCur = 0; c->posCur = 0; c->gridValid = false; c->maskValid = false;
     }
     return SPH_OK;
 }
@@ -1214,7 +1238,7 @@ int sph_slab_upload(sph_ctx* c, const sph_slab_record* records, int n) {
         int rc = allocCapacity(c, n);
         if (rc) return rc;
     }
-    c->cur = 0; c->velCur = 0; c->gridValid = false; c->maskValid = false;
+    c->cur = 0; c->velCur = 0; c->posCur = 0; c->gridValid = false; c->maskValid = false;
     c->n = n;
     c->ownedRef.keys = nullptr;       // everything uploaded is owned
     c->filter.active = 0;             // a rebuild that was waiting for its grid build is void

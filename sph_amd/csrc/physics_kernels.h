@@ -448,34 +448,70 @@ __device__ __forceinline__ ForceSelf force_load_self(const DevParams& P, int s, 
     return me;
 }
 
+// sph_step_frame on one GPU: the frame's tail -- CS_VvFullStep + CS_BoundObs (+ CS_VelocityDamping after the last
+// sub-step), k_full_bound_damp below -- applied by the force kernel itself to the particle it has just finished, in
+// registers: the same statements on the same values, so positions and velocities are bit-identical to the separate
+// pass, which then does not run (one launch and 48 B read + 16 B written per particle less).  The new position goes to
+// the OTHER position buffer (posOut): a wave that fell back to the scan path still reads its neighbours' positions
+// from posM while other workgroups finish.
+struct TailArgs {
+    float4* posOut;                  // null = tail not fused
+    int damp;
+    int* blockCollide;               // per-workgroup OBB collision counts (block_count)
+    int* counters;
+};
+__device__ __forceinline__ bool bound_obs_body(const DevParams& P, float4& p, float4& v);
+__device__ __forceinline__ void damp_velocity(float4& v);
+__device__ __forceinline__ void block_count(bool pred, int* __restrict__ blockCount);
+__device__ __forceinline__ void count_non_finite(const float4& p, const float4& v, bool counted, int* __restrict__ counters);
+
+template <bool TAIL>
 __device__ __forceinline__ void force_finish(const DevParams& P, ForceAcc& A, const ForceSelf& me,
                                              float4* __restrict__ acc, float4* __restrict__ velOut,
-                                             int zeroDeadAcc) {
+                                             int zeroDeadAcc, const TailArgs& T) {
     const int s = me.s;
-    if (s >= P.n) return;
-    if (!me.live) {
-        velOut[s] = me.v;
-        if (zeroDeadAcc) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);   // what the elided CS_Clear would have left
-        return;
-    }
-    {
-        // explicit operations, contraction off: this tail is inlined into two kernels and a particle
-        // must get the same bits whichever of them handles it
-#pragma clang fp contract(off)
-        const float gradMag = sqrtf((A.cgx * A.cgx + A.cgy * A.cgy) + A.cgz * A.cgz);   // compute:285
-        if (gradMag > P.stThreshold) {
-            const float curvature = A.cl / (gradMag + 1e-6f);
-            const float st = -P.sigma * curvature / gradMag;
-            A.fx = fmaf(st, A.cgx, A.fx); A.fy = fmaf(st, A.cgy, A.fy); A.fz = fmaf(st, A.cgz, A.fz);
-        }
-        const float invD = 1.0f / me.densitySelf;
-        acc[s] = make_float4(A.fx * invD, A.fy * invD, A.fz * invD, 0.f);            // compute:293
+    bool collided = false;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), v = p;
+    if (s < P.n) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 vo = me.v;
-        if (A.norm > 1e-6f) {                                                        // compute:296-300
-            const float sc = P.xsphEps / A.norm;
-            vo.x = fmaf(A.vcx, sc, vo.x); vo.y = fmaf(A.vcy, sc, vo.y); vo.z = fmaf(A.vcz, sc, vo.z);
+        if (me.live) {
+            // explicit operations, contraction off: this tail is inlined into several kernels and a particle
+            // must get the same bits whichever of them handles it
+#pragma clang fp contract(off)
+            const float gradMag = sqrtf((A.cgx * A.cgx + A.cgy * A.cgy) + A.cgz * A.cgz);   // compute:285
+            if (gradMag > P.stThreshold) {
+                const float curvature = A.cl / (gradMag + 1e-6f);
+                const float st = -P.sigma * curvature / gradMag;
+                A.fx = fmaf(st, A.cgx, A.fx); A.fy = fmaf(st, A.cgy, A.fy); A.fz = fmaf(st, A.cgz, A.fz);
+            }
+            const float invD = 1.0f / me.densitySelf;
+            a = make_float4(A.fx * invD, A.fy * invD, A.fz * invD, 0.f);                 // compute:293
+            if (A.norm > 1e-6f) {                                                        // compute:296-300
+                const float sc = P.xsphEps / A.norm;
+                vo.x = fmaf(A.vcx, sc, vo.x); vo.y = fmaf(A.vcy, sc, vo.y); vo.z = fmaf(A.vcz, sc, vo.z);
+            }
         }
-        velOut[s] = vo;
+        if (!TAIL) {
+            velOut[s] = vo;
+            // a skipped particle keeps its acceleration unless the elided CS_Clear would have zeroed it
+            if (me.live || zeroDeadAcc) acc[s] = a;
+        } else {
+            // (TAIL is only launched by sph_step_frame, where zeroDeadAcc is set: a skipped particle's acceleration is 0)
+#pragma clang fp contract(off)
+            p = me.p; v = vo;
+            const float hdt = 0.5f * P.dt;
+            v.x += hdt * a.x; v.y += hdt * a.y; v.z += hdt * a.z;                        // compute:332
+            collided = bound_obs_body(P, p, v);
+            if (T.damp) damp_velocity(v);
+            T.posOut[s] = p;
+            velOut[s] = v;
+            acc[s] = a;
+        }
+    }
+    if (TAIL) {
+        count_non_finite(p, v, s < P.n, T.counters);
+        block_count(collided, T.blockCollide);
     }
 }
 
@@ -495,7 +531,7 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_rows(DevParams P, const f
     ForceAcc A{0.0f, P.gravity * me.densitySelf, 0.0f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // compute:219
     const int3 c = search_cell(P, me.p.x, me.p.y, me.p.z);
     force_scan(P, A, me, c, capped, posM, velIn, rhoP, cellCum, queue);
-    force_finish(P, A, me, acc, velOut, zeroDeadAcc);
+    force_finish<false>(P, A, me, acc, velOut, zeroDeadAcc, TailArgs{nullptr, 0, nullptr, nullptr});
 }
 
 // Hit path.  PRECONDITION (kept by the host, libsph_hip.hip `maskValid`): hitMask was written by
@@ -507,7 +543,7 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_rows(DevParams P, const f
 // the same viscosity (ph.m0, ph.v0: true of all the BASELINE configurations, whose phases differ in rest density only),
 // so there is nothing to decode.  The host picks the mode (libsph_hip.hip); in slab mode it takes a packed mode only
 // after it has read the record / phase-table mismatch flag as clean for this frame's records.
-template <int MODE>
+template <int MODE, bool TAIL>
 __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const float4* __restrict__ posM,
                                                             const float4* __restrict__ velIn,
                                                             const float2* __restrict__ rhoP,
@@ -517,7 +553,7 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
                                                             const uint32_t* __restrict__ hitMask, int maskStride,
                                                             const float4* __restrict__ nbrA,
                                                             const float4* __restrict__ nbrB, PhaseConsts ph,
-                                                            int zeroDeadAcc, int rowSlack) {
+                                                            int zeroDeadAcc, int rowSlack, TailArgs tail) {
     // one buffer, two uses: (a) per lane the non-empty mask words and the slot of their bit 0,
     // (b) the scan path's hit FIFO.  Every thread only touches its own column.
     static_assert(kMaskWords + 9 >= kHitQueue, "the FIFO lives in the word list's LDS");
@@ -675,7 +711,7 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
             compute(SB);
         }
     }
-    force_finish(P, A, me, acc, velOut, zeroDeadAcc);
+    force_finish<TAIL>(P, A, me, acc, velOut, zeroDeadAcc, tail);
 }
 
 // CS_VvHalfStep (compute:309-319)
