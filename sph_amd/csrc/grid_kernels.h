@@ -26,7 +26,7 @@ __device__ __forceinline__ int3 cell_unclamped(const DevParams& P, float x, floa
 // <= c -- IS the offset table of a counting sort by cell, so the build is:
 //   k_hash_count : cell of every slot; one returning atomicAdd per particle on T[cell] gives its
 //                  arrival number inside the cell (order of arrival is arbitrary);
-//   k_cum_*      : in-place inclusive prefix sum over the cells (int4, 4096 cells per workgroup);
+//   k_cum_*      : inclusive prefix sum over the cells (int4, 4096 cells per workgroup) into the cumulative table;
 //   k_place      : bucket slot = cellCum[cell] + arrival;
 //   k_rank_move (below) then orders every cell by particle id, which removes the arbitrariness:
 //                  the result is the unique (cell, id) order whatever order the atomics ran in.
@@ -42,6 +42,12 @@ __device__ __forceinline__ int3 cell_unclamped(const DevParams& P, float x, floa
 // the counting sort itself is the compaction, no separate copy of the survivors.
 // Who owned a slot at the last grid build: its key there, decoded with THAT build's local grid (the slab's
 // cut may have moved since: sph_slab_configure before the next build).  keys == null: everything was owned.
+constexpr int kScanVec = 4;                              // int4 per thread per round
+constexpr int kScanRounds = 4;
+constexpr int kScanTile = kBlock * kScanVec * kScanRounds;   // 4096 cells per block
+constexpr int kScanTileLog = 12;
+static_assert(1 << kScanTileLog == kScanTile, "tile of the table scan");
+
 struct OwnedRef {
     const uint32_t* keys;
     int rx, ownLo, ownHi;            // local resolution and owned local planes of the build that wrote `keys`
@@ -64,7 +70,8 @@ struct SlabFilter {
 
 __global__ __launch_bounds__(kBlock) void k_hash_count(DevParams P, const float4* __restrict__ posM,
                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ arrival,
-                                                       int* __restrict__ T, int* __restrict__ counters, SlabFilter F) {
+                                                       int* __restrict__ T, int* __restrict__ counters, SlabFilter F,
+                                                       uint8_t* __restrict__ tileTouched) {
     int s = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     bool oog = false;
@@ -104,15 +111,20 @@ __global__ __launch_bounds__(kBlock) void k_hash_count(DevParams P, const float4
     const unsigned long long above = (headLane == 63) ? 0ull : heads & ~((2ull << headLane) - 1ull);
     const int runLen = (above ? __builtin_ctzll(above) : 64) - headLane;
     int base = 0;
-    if (head && key != 0xFFFFFFFFu) base = atomicAdd(&T[key], runLen);
+    if (head && key != 0xFFFFFFFFu) {
+        base = atomicAdd(&T[key], runLen);
+        tileTouched[key >> kScanTileLog] = 1;            // plain store: every writer stores the same value
+    }
     base = __shfl(base, headLane);
     if (s < P.n) arrival[s] = (uint32_t)(base + (lane - headLane));
     unsigned long long m = __ballot(oog);
     if (m && lane == 0) atomicAdd(&counters[SPH_CTR_OUT_OF_GRID], __popcll(m));
 }
 
-// Zeroes the cumulative table (int4 at a time) and, when a grid build follows, the per-build
-// counters (bin overflow, out of grid, max plane shift) -- one launch instead of two fills.
+// CS_ClearGrid (compute:104-111) as a dispatchable kernel: zeroes the cumulative table (int4 at a time).  A grid
+// build does not need it: the COUNT array the build accumulates into is left all-zero by k_cum_write (which reads
+// every touched tile anyway), the cumulative table is a second array that k_cum_write overwrites completely, and the
+// per-build counters alternate between two sets, the idle one zeroed by k_cum_block_sum.
 __global__ __launch_bounds__(kBlock) void k_clear_table(int4* __restrict__ T4, long long n4, int* __restrict__ counters) {
     const long long base = (long long)blockIdx.x * (kBlock * 4) + threadIdx.x;
 #pragma unroll
@@ -124,9 +136,6 @@ __global__ __launch_bounds__(kBlock) void k_clear_table(int4* __restrict__ T4, l
         counters[threadIdx.x] = 0;
 }
 
-constexpr int kScanVec = 4;                              // int4 per thread per round
-constexpr int kScanRounds = 4;
-constexpr int kScanTile = kBlock * kScanVec * kScanRounds;   // 4096 cells per block
 
 __device__ __forceinline__ int wave_incl_sum(int v, int lane) {
 #pragma unroll
@@ -138,9 +147,19 @@ __device__ __forceinline__ int wave_incl_sum(int v, int lane) {
 }
 
 // cells4 = number of int4 groups (the table is padded to a multiple of 4 cells with zeros)
+// Tiles no particle was counted into (tileTouched == 0: k_hash_count marks the tiles it adds to) are all-zero and
+// are not read.  Workgroup 0 also zeroes the per-build counters of the NEXT build (the idle set).
 __global__ __launch_bounds__(kBlock) void k_cum_block_sum(const int4* __restrict__ T4, long long cells4,
-                                                          int* __restrict__ blockSum) {
+                                                          int* __restrict__ blockSum,
+                                                          const uint8_t* __restrict__ tileTouched,
+                                                          int* __restrict__ idleCounters) {
     __shared__ int ws[4];
+    if (blockIdx.x == 0 && threadIdx.x >= SPH_CTR_BIN_OVERFLOW && threadIdx.x < SPH_CTR_COUNT)
+        idleCounters[threadIdx.x] = 0;
+    if (!tileTouched[blockIdx.x]) {                      // workgroup-uniform
+        if (threadIdx.x == 0) blockSum[blockIdx.x] = 0;
+        return;
+    }
     const long long base = (long long)blockIdx.x * (kBlock * kScanRounds) + threadIdx.x;
     int m = 0;
 #pragma unroll
@@ -159,11 +178,14 @@ __global__ __launch_bounds__(kBlock) void k_cum_block_sum(const int4* __restrict
     if (threadIdx.x == 0) blockSum[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
-// in-place inclusive prefix sum of one 4096-cell tile.  Its seed -- the sum of all earlier tiles -- is
-// reduced here from the per-tile sums (a few hundred to a few thousand ints, L2-resident) instead of
-// by a separate one-workgroup scan kernel.
-__global__ __launch_bounds__(kBlock) void k_cum_write(int4* __restrict__ T4, long long cells4,
-                                                      const int* __restrict__ blockSum) {
+// Inclusive prefix sum of one 4096-cell tile of the COUNT array into the cumulative table `out`; the counts are
+// zeroed on the way (so the next build finds the array all-zero and no clearing pass exists).  The tile's seed -- the
+// sum of all earlier tiles -- is reduced here from the per-tile sums (a few hundred to a few thousand ints,
+// L2-resident) instead of by a separate one-workgroup scan kernel.  An untouched tile (no particle counted into it)
+// is not read: its 4096 entries are the seed.
+__global__ __launch_bounds__(kBlock) void k_cum_write(int4* __restrict__ T4, int4* __restrict__ out4, long long cells4,
+                                                      const int* __restrict__ blockSum,
+                                                      uint8_t* __restrict__ tileTouched) {
     __shared__ int ws[4];
     __shared__ int seed[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -172,13 +194,23 @@ __global__ __launch_bounds__(kBlock) void k_cum_write(int4* __restrict__ T4, lon
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
     if (lane == 0) seed[wave] = part;
+    const bool touched = tileTouched[blockIdx.x] != 0;                      // workgroup-uniform
     __syncthreads();
     int carry = (seed[0] + seed[1]) + (seed[2] + seed[3]);
     const long long base = (long long)blockIdx.x * (kBlock * kScanRounds) + threadIdx.x;
+    if (!touched) {
+#pragma unroll
+        for (int r = 0; r < kScanRounds; r++) {
+            const long long i = base + (long long)r * kBlock;
+            if (i < cells4) out4[i] = make_int4(carry, carry, carry, carry);
+        }
+        return;
+    }
 #pragma unroll 1
     for (int r = 0; r < kScanRounds; r++) {
         const long long i = base + (long long)r * kBlock;
         int4 v = (i < cells4) ? T4[i] : make_int4(0, 0, 0, 0);
+        if (i < cells4) T4[i] = make_int4(0, 0, 0, 0);
         v.y += v.x; v.z += v.y; v.w += v.z;                                 // thread-local
         const int incl = wave_incl_sum(v.w, lane);
         __syncthreads();                                                    // ws free again
@@ -186,9 +218,10 @@ __global__ __launch_bounds__(kBlock) void k_cum_write(int4* __restrict__ T4, lon
         __syncthreads();
         int off = carry + (incl - v.w);
         for (int w = 0; w < wave; w++) off += ws[w];
-        if (i < cells4) T4[i] = make_int4(v.x + off, v.y + off, v.z + off, v.w + off);
+        if (i < cells4) out4[i] = make_int4(v.x + off, v.y + off, v.z + off, v.w + off);
         carry += (ws[0] + ws[1]) + (ws[2] + ws[3]);
     }
+    if (threadIdx.x == 0) tileTouched[blockIdx.x] = 0;                      // only this workgroup reads it
 }
 
 // bucket slot of every particle; the slot's key, source slot and id travel with it

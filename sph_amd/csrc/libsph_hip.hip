@@ -68,9 +68,12 @@ struct sph_ctx {
     long long cells = 0;              // rx * ry * rz, the reference's cell count
     long long tableCells = 0;         // entries of the tiled cell table (rows padded to whole tiles)
     long long cellCapacity = 0;
-    int* cumBase = nullptr;           // allocation behind the cumulative cell table
-    int* cumT = nullptr;              // T[c] = #particles with cell <= c (16-byte aligned, T[-1] = 0)
+    int* cumBase = nullptr;           // allocation behind the COUNT array of the grid build
+    int* cumT = nullptr;              // counts per cell during a build (16-byte aligned); all-zero between builds
+    int* cumOutBase = nullptr;        // allocation behind the cumulative cell table
+    int* cumOut = nullptr;            // T[c] = #particles with cell <= c (16-byte aligned, T[-1] = 0)
     int* cellCum = nullptr;           // = T - 1: cellCum[c] = #particles with cell < c; [cells + 1] entries
+    uint8_t* tileTouched = nullptr;   // per 4096-cell tile of the count array: a particle was counted into it
     int* cumBlocks = nullptr;         // particles per 4096-cell tile of the table (k_cum_block_sum), the seeds of its scan
     uint32_t* keys[2] = {nullptr, nullptr};
     uint32_t* vals[2] = {nullptr, nullptr};
@@ -93,7 +96,11 @@ struct sph_ctx {
     bool debug = false;               // SPH_HIP_DEBUG=1: report on stderr which force kernel runs
     int lastForceVariant = -1;
 
-    int* counters = nullptr;          // SPH_CTR_COUNT ints on the device
+    // Two sets of SPH_CTR_COUNT ints: the per-build counters (bin overflow, out of grid, plane shift, band misses,
+    // non-finite) alternate between them, every grid build starts on the set its predecessor zeroed on the way
+    // (k_cum_block_sum), so no fill precedes a build.  The collision counter always lives in set 0.
+    int* countersBase = nullptr;
+    int* counters = nullptr;          // the current set (what the kernels and sph_read_counter use)
     // Collision counter (SPH_CTR_COLLISIONS), kept lazily: the boundary pass leaves one count per workgroup
     // in blockCollide; they are folded into the device counter only when somebody reads it (or before the
     // next pass overwrites them).  SPH.cs:190 resets the counter every frame and reads it never, so the
@@ -250,8 +257,8 @@ void freeParticles(sph_ctx* c) {
 }
 
 void freeGrid(sph_ctx* c) {
-    devFree(c->cumBase); devFree(c->cumBlocks);
-    c->cumT = c->cellCum = nullptr;
+    devFree(c->cumBase); devFree(c->cumOutBase); devFree(c->cumBlocks); devFree(c->tileTouched);
+    c->cumT = c->cumOut = c->cellCum = nullptr;
     c->cellCapacity = 0; c->cells = 0; c->tableCells = 0;
 }
 
@@ -402,13 +409,14 @@ int applyPhaseTable(sph_ctx* c) {
 }
 
 // CS_ClearGrid (compute:104-111): a bin is a range of the cumulative table here, so clearing = zeroing
-// the table.  One launch also resets the per-build counters when a build follows.
-int clearGrid(sph_ctx* c, bool resetBuildCounters = false) {
+// the table.  Only the kernel-granular dispatch runs it (and the empty-slab case): a grid build overwrites the
+// whole table and needs no clearing pass.
+int clearGrid(sph_ctx* c) {
     // T[-4 .. cells padded to int4): zero = "no particle in any cell"
     const size_t padded = ((size_t)c->tableCells + 3) / 4 * 4 + 4;
     const long long n4 = (long long)(padded / 4);
-    LAUNCH_T(c, resetBuildCounters ? E_GRID0 : -1, -1, k_clear_table, dim3((unsigned)((n4 + kBlock * 4 - 1) / (kBlock * 4))),
-             (int4*)c->cumBase, n4, resetBuildCounters ? c->counters : (int*)nullptr);
+    hipLaunchKernelGGL(k_clear_table, dim3((unsigned)((n4 + kBlock * 4 - 1) / (kBlock * 4))), dim3(kBlock), 0, c->stream,
+                       (int4*)c->cumOutBase, n4, (int*)nullptr);
     CHECK_LAUNCH(c);
     c->gridValid = false;
     c->maskValid = false;
@@ -422,21 +430,28 @@ int clearGrid(sph_ctx* c, bool resetBuildCounters = false) {
 int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
     const int n = c->n;
     const int nb = blocksFor(n);
-    int rc = clearGrid(c, true);
-    if (rc) return rc;
+    c->gridValid = false;
+    c->maskValid = false;
+    c->cachedShift = -1;
+    c->cachedMisses = -1;
+    // per-build counters: this build and its frame use the set the last build zeroed (k_cum_block_sum)
+    int* const idleCounters = c->counters;
+    c->counters = c->counters == c->countersBase ? c->countersBase + SPH_CTR_COUNT : c->countersBase;
     const SlabFilter filter = c->filter;
     c->filter.active = 0;
     c->slabMismatchClean = false;
     if (c->slab) c->ownedRef = OwnedRef{c->keys[1], c->dp.rx, c->dp.ownLo, c->dp.ownHi};   // as of THIS build
     if (n == 0) {   // an empty slab: the zeroed table is its grid
+        if (int rc = clearGrid(c)) return rc;
+        HIP_TRY(c, hipMemsetAsync(idleCounters + SPH_CTR_BIN_OVERFLOW, 0, sizeof(int) * (SPH_CTR_COUNT - SPH_CTR_BIN_OVERFLOW), c->stream));
         c->gridValid = true;
         return SPH_OK;
     }
     StateSet src = curSet(c);
     // keys[0] = cell per old slot, vals[0] = arrival number; keys[1] / vals[1] / sid = key, source slot
     // and id per bucket slot
-    hipLaunchKernelGGL(k_hash_count, dim3(nb), dim3(kBlock), 0, c->stream, c->dp, src.posM, c->keys[0], c->vals[0],
-                       c->cumT, c->counters, filter);
+    LAUNCH_T(c, E_GRID0, -1, k_hash_count, dim3(nb), c->dp, (const float4*)src.posM, c->keys[0], c->vals[0], c->cumT, c->counters,
+             filter, c->tileTouched);
     CHECK_LAUNCH(c);
     {   // counts -> cumulative cell table
         const long long cells4 = (c->tableCells + 3) / 4;
@@ -444,8 +459,9 @@ int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
         // (counting the tile sums in k_hash_count instead -- one atomic per wave and 4096-cell tile -- was tried: the fluid
         // sits in a few dozen tiles, the atomics serialise on their addresses and the grid build went from 74 to 119 us)
         hipLaunchKernelGGL(k_cum_block_sum, dim3(cb), dim3(kBlock), 0, c->stream, (const int4*)c->cumT, cells4,
-                           c->cumBlocks);
-        hipLaunchKernelGGL(k_cum_write, dim3(cb), dim3(kBlock), 0, c->stream, (int4*)c->cumT, cells4, c->cumBlocks);
+                           c->cumBlocks, (const uint8_t*)c->tileTouched, idleCounters);
+        hipLaunchKernelGGL(k_cum_write, dim3(cb), dim3(kBlock), 0, c->stream, (int4*)c->cumT, (int4*)c->cumOut, cells4,
+                           (const int*)c->cumBlocks, c->tileTouched);
     }
     c->sortedKeys = c->keys[1];
     uint32_t* perm = c->vals[1];
@@ -492,7 +508,7 @@ int buildGrid(sph_ctx* c, bool fuseHalfStep = false) {
 int foldCollisions(sph_ctx* c) {
     if (c->collideFoldBlocks <= 0) return SPH_OK;
     hipLaunchKernelGGL(k_sum_into, dim3(1), dim3(kBlock), 0, c->stream, c->blockCollide, c->collideFoldBlocks,
-                       c->counters + SPH_CTR_COLLISIONS, c->collisionsResetPending ? 1 : 0);
+                       c->countersBase + SPH_CTR_COLLISIONS, c->collisionsResetPending ? 1 : 0);
     CHECK_LAUNCH(c);
     c->collideFoldBlocks = 0;
     c->collisionsResetPending = false;
@@ -701,14 +717,15 @@ int sph_create(sph_ctx** out, int device_id) {
         for (int k = 0; k < kNumEvents; k++) (void)hipEventCreateWithFlags(&c->ev[r][k], c->eventFlags);
     (void)hipEventCreateWithFlags(&c->packEvent, hipEventDisableTiming);
     if (hipHostMalloc((void**)&c->hostInts, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
-        hipMalloc((void**)&c->counters, SPH_CTR_COUNT * sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&c->countersBase, 2 * SPH_CTR_COUNT * sizeof(int)) != hipSuccess ||
         hipMalloc((void**)&c->slabCounts, 4 * sizeof(int)) != hipSuccess ||
         hipMalloc((void**)&c->phaseMismatch, sizeof(int)) != hipSuccess ||
         hipMemsetAsync(c->phaseMismatch, 0, sizeof(int), c->stream) != hipSuccess ||
-        hipMemsetAsync(c->counters, 0, SPH_CTR_COUNT * sizeof(int), c->stream) != hipSuccess) {
+        hipMemsetAsync(c->countersBase, 0, 2 * SPH_CTR_COUNT * sizeof(int), c->stream) != hipSuccess) {
         sph_destroy(c);
         return SPH_E_NOMEM;
     }
+    c->counters = c->countersBase;
     *out = c;
     return SPH_OK;
 }
@@ -719,7 +736,8 @@ int sph_destroy(sph_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     freeParticles(c);
     freeGrid(c);
-    devFree(c->counters);
+    devFree(c->countersBase);
+    c->counters = nullptr;
     if (c->hostInts) (void)hipHostFree(c->hostInts);
     c->hostInts = nullptr;
     devFree(c->slabCounts);
@@ -861,10 +879,18 @@ int sph_resize_grid(sph_ctx* c, int rx, int ry, int rz, int max_per_cell) {
         freeGrid(c);
         long long want = table + table / 4;
         if (want > 0x7FFFFFF0ll) want = 0x7FFFFFF0ll;
+        const size_t tiles = (size_t)((want + kScanTile - 1) / kScanTile) + 1;
         int rc = devAlloc(c, &c->cumBase, (size_t)want + 16);
-        if (!rc) { c->cumT = c->cumBase + 4; c->cellCum = c->cumT - 1; }
-        if (!rc) rc = devAlloc(c, &c->cumBlocks, (size_t)((want + kScanTile - 1) / kScanTile));
+        if (!rc) rc = devAlloc(c, &c->cumOutBase, (size_t)want + 16);
+        if (!rc) { c->cumT = c->cumBase + 4; c->cumOut = c->cumOutBase + 4; c->cellCum = c->cumOut - 1; }
+        if (!rc) rc = devAlloc(c, &c->cumBlocks, tiles);
+        if (!rc) rc = devAlloc(c, &c->tileTouched, tiles);
         if (rc) { freeGrid(c); return rc; }
+        // invariant of the grid build: the count array and the tile flags are all-zero between builds (k_cum_write
+        // restores it); the cumulative table's T[-1] = 0 is never written again
+        HIP_TRY(c, hipMemsetAsync(c->cumBase, 0, sizeof(int) * ((size_t)want + 16), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->cumOutBase, 0, sizeof(int) * ((size_t)want + 16), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->tileTouched, 0, tiles, c->stream));
         c->cellCapacity = want;
     }
     c->rx = rx; c->ry = ry; c->rz = rz; c->cap = max_per_cell; c->cells = cells; c->tableCells = table;
@@ -1057,7 +1083,7 @@ int sph_read_counter(sph_ctx* c, int which, int* value) {
         if (int rcFold = foldCollisions(c)) return rcFold;
         if (c->collisionsResetPending) { *value = 0; return SPH_OK; }
     }
-    if (int rcRead = readInts(c, c->counters + which, 1, value)) return rcRead;
+    if (int rcRead = readInts(c, (which == SPH_CTR_COLLISIONS ? c->countersBase : c->counters) + which, 1, value)) return rcRead;
     return SPH_OK;
 }
 
