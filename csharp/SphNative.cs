@@ -97,6 +97,7 @@ namespace SphHip
         [DllImport(Lib)] public static extern IntPtr sph_version();
         [DllImport(Lib)] public static extern int sph_alloc_particles(IntPtr ctx, int n);
         [DllImport(Lib)] public static extern int sph_upload_particles(IntPtr ctx, [In] SphParticle[] aos72, int n);
+        [DllImport(Lib)] public static extern int sph_upload_particles_in_place(IntPtr ctx, [In] SphParticle[] aos72, int n);
         [DllImport(Lib)] public static extern int sph_download_particles(IntPtr ctx, [Out] SphParticle[] aos72, int n);
         [DllImport(Lib)] public static extern int sph_export_particles_device(IntPtr ctx, IntPtr devAos72, int n);
         [DllImport(Lib)] public static extern int sph_resize_grid(IntPtr ctx, int rx, int ry, int rz, int maxPerCell);
@@ -113,6 +114,7 @@ namespace SphHip
         [DllImport(Lib)] public static extern int sph_download_grid(IntPtr ctx, [Out] int[] cellStart, [Out] int[] cellEnd,
                                                                     [Out] int[] sortedIds, [Out] uint[] cellOfParticle);
         [DllImport(Lib)] public static extern int sph_download_neighbors(IntPtr ctx, [Out] int[] counts, [Out] int[] lists, int maxNeighbors);
+        [DllImport(Lib)] public static extern int sph_download_hit_lists(IntPtr ctx, [Out] int[] counts, [Out] int[] lists, int maxNeighbors, out int maskState);
         [DllImport(Lib)] public static extern int sph_get_timings(IntPtr ctx, out SphTimings t);
         [DllImport(Lib)] public static extern int sph_particle_count(IntPtr ctx, out int n);
     }

@@ -160,6 +160,10 @@ const char* sph_version(void);
 int  sph_alloc_particles(sph_ctx* ctx, int n);
 /* SPH.cs:280 / 297  particleBuffer.SetData(array): n records of 72 B in id order. */
 int  sph_upload_particles(sph_ctx* ctx, const void* aos72, int n);
+/* particleBuffer.SetData(array) in the MIDDLE of a frame: the reference's SetData never touches GridCounts /
+ * GridIndices (SPH.cs:280, 297 vs 156-157), so the records are written over the particles where they sit and the grid
+ * of the last CS_BuildGrid stays valid.  What lock-step tests use to re-synchronise between sub-steps. */
+int  sph_upload_particles_in_place(sph_ctx* ctx, const void* aos72, int n);
 /* SPH.cs:287  particleBuffer.GetData(array): n records of 72 B, id order.  Synchronises. */
 int  sph_download_particles(sph_ctx* ctx, void* aos72, int n);
 /* Render feed.  In the reference the renderer binds the simulation's ComputeBuffer itself
@@ -219,6 +223,15 @@ int  sph_download_grid(sph_ctx* ctx, int32_t* cell_start, int32_t* cell_end,
  * then bin order; compute:158-181).  counts[n]; lists[n*max_neighbors], entries beyond
  * counts[i] are set to -1; counts[i] may exceed max_neighbors (then the list is truncated). */
 int  sph_download_neighbors(sph_ctx* ctx, int32_t* counts, int32_t* lists, int max_neighbors);
+/* The hit lists CS_ForceXSPH is about to walk: the bit mask CS_DensityPressure's engine kernel left for the force kernel
+ * (one bit per candidate slot, the reference's loops compute:170-181 / 241-246 evaluated once instead of twice), decoded
+ * into ids in visiting order -- the artefact the force kernel actually consumes, where sph_download_neighbors re-walks
+ * the candidates.  Same layout as sph_download_neighbors; counts[i] = -1 for a particle without a usable mask (its
+ * rows need more words than a mask row holds; its wave scans instead).  *mask_state: 1 = lists written, 0 = no fresh
+ * mask exists (positions or grid changed since the last CS_DensityPressure: CS_ForceXSPH would scan), 2 = a bin
+ * overflowed its capacity at the last grid build (rule O2: nothing is recorded, the capped 27-cell scan runs);
+ * for 0 and 2 counts / lists are not touched.  Not available in slab mode.  Synchronises. */
+int  sph_download_hit_lists(sph_ctx* ctx, int32_t* counts, int32_t* lists, int max_neighbors, int* mask_state);
 int  sph_get_timings(sph_ctx* ctx, sph_timings* out);
 /* Raw device pointers of the internal SoA buffers, for zero-copy views (torch, RCCL).
  * name: "posM" "velV" "acc" "rhoP" "rho0" "origId".  Valid until the next alloc/destroy. */

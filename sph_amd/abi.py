@@ -27,10 +27,10 @@ PLANE_COUNTS_MAX = 8192      # SPH_PLANE_COUNTS_MAX
 # every symbol include/sph_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "sph_create", "sph_destroy", "sph_last_error", "sph_version", "sph_alloc_particles",
-    "sph_upload_particles", "sph_download_particles", "sph_export_particles_device", "sph_resize_grid", "sph_set_params",
+    "sph_upload_particles", "sph_upload_particles_in_place", "sph_download_particles", "sph_export_particles_device", "sph_resize_grid", "sph_set_params",
     "sph_set_delta_time", "sph_set_phase_table", "sph_set_phase_ids", "sph_apply_phase_table",
     "sph_dispatch", "sph_step_frame", "sph_synchronize", "sph_reset_counter", "sph_read_counter",
-    "sph_download_grid", "sph_download_neighbors", "sph_get_timings", "sph_device_pointer",
+    "sph_download_grid", "sph_download_neighbors", "sph_download_hit_lists", "sph_get_timings", "sph_device_pointer",
     "sph_get_stream", "sph_slab_configure", "sph_slab_reserve", "sph_slab_upload", "sph_slab_download",
     "sph_slab_pack", "sph_slab_rebuild", "sph_slab_arm_pack", "sph_slab_pack_wait", "sph_slab_plane_counts",
     "sph_slab_plane_counts_noalloc", "sph_particle_count",
@@ -147,6 +147,7 @@ def load_library() -> C.CDLL:
     lib.sph_version.restype = C.c_char_p
     lib.sph_alloc_particles.argtypes = [vp, ip]
     lib.sph_upload_particles.argtypes = [vp, vp, ip]
+    lib.sph_upload_particles_in_place.argtypes = [vp, vp, ip]
     lib.sph_download_particles.argtypes = [vp, vp, ip]
     lib.sph_export_particles_device.argtypes = [vp, vp, ip]
     lib.sph_resize_grid.argtypes = [vp, ip, ip, ip, ip]
@@ -162,6 +163,7 @@ def load_library() -> C.CDLL:
     lib.sph_read_counter.argtypes = [vp, ip, C.POINTER(ip)]
     lib.sph_download_grid.argtypes = [vp, vp, vp, vp, vp]
     lib.sph_download_neighbors.argtypes = [vp, vp, vp, ip]
+    lib.sph_download_hit_lists.argtypes = [vp, vp, vp, ip, C.POINTER(ip)]
     lib.sph_get_timings.argtypes = [vp, C.POINTER(SphTimings)]
     lib.sph_device_pointer.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64)]
     lib.sph_get_stream.argtypes = [vp, C.POINTER(vp)]
@@ -226,6 +228,11 @@ class Engine:
         aos = np.ascontiguousarray(aos, dtype=np.float32).reshape(-1, PARTICLE_FLOATS)
         self._ck(self.lib.sph_upload_particles(self.h, _ptr(aos), aos.shape[0]))
 
+    def upload_particles_in_place(self, aos: np.ndarray):
+        """SetData in the middle of a frame: slot order and grid stay (sph_upload_particles_in_place)."""
+        aos = np.ascontiguousarray(aos, dtype=np.float32).reshape(-1, PARTICLE_FLOATS)
+        self._ck(self.lib.sph_upload_particles_in_place(self.h, _ptr(aos), aos.shape[0]))
+
     def download_particles(self) -> np.ndarray:
         out = np.empty((self.n, PARTICLE_FLOATS), dtype=np.float32)
         self._ck(self.lib.sph_download_particles(self.h, _ptr(out), self.n))
@@ -289,6 +296,15 @@ class Engine:
         lists = np.full((self.n, max_neighbors), -1, dtype=np.int32)
         self._ck(self.lib.sph_download_neighbors(self.h, _ptr(counts), _ptr(lists), max_neighbors))
         return counts, lists
+
+    def download_hit_lists(self, max_neighbors):
+        """(mask_state, counts, lists): the force kernel's hit mask decoded into ids (sph_download_hit_lists).
+        mask_state 1 = lists valid, 0 = no fresh mask, 2 = a bin overflowed (capped scan path, nothing recorded)."""
+        counts = np.full(self.n, -3, dtype=np.int32)
+        lists = np.full((self.n, max_neighbors), -1, dtype=np.int32)
+        state = C.c_int(0)
+        self._ck(self.lib.sph_download_hit_lists(self.h, _ptr(counts), _ptr(lists), max_neighbors, C.byref(state)))
+        return state.value, counts, lists
 
     def get_timings(self) -> dict:
         t = SphTimings()

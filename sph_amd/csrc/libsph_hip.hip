@@ -675,6 +675,28 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
     return SPH_OK;
 }
 
+// Shared by the two list exports: device scratch for counts[n] and lists[n * max], run `launch`, copy back.
+template <class Launch>
+int exportLists(sph_ctx* c, int32_t* counts, int32_t* lists, int max_neighbors, Launch launch) {
+    int *dCounts = nullptr, *dLists = nullptr;
+    const size_t lb = sizeof(int) * (size_t)c->n * (size_t)max_neighbors;
+    HIP_TRY(c, hipMalloc((void**)&dCounts, sizeof(int) * (size_t)c->n));
+    if (lists && lb) {
+        hipError_t e = hipMalloc((void**)&dLists, lb);
+        if (e != hipSuccess) { (void)hipFree(dCounts); return fail(c, SPH_E_NOMEM, "neighbour list alloc failed"); }
+        (void)hipMemsetAsync(dLists, 0xFF, lb, c->stream);   // unused tail entries read back as -1
+    }
+    launch(dCounts, dLists);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(counts, dCounts, sizeof(int) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && dLists) e = hipMemcpyAsync(lists, dLists, lb, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dCounts);
+    if (dLists) (void)hipFree(dLists);
+    if (e != hipSuccess) return fail(c, SPH_E_HIP, "neighbour export failed: %s", hipGetErrorString(e));
+    return SPH_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1137,24 +1159,52 @@ int sph_download_neighbors(sph_ctx* c, int32_t* counts, int32_t* lists, int max_
     if (rc) return rc;
     if (c->slab) return fail(c, SPH_E_STATE, "neighbour export is indexed by id: not available in slab mode");
     HIP_TRY(c, hipSetDevice(c->device));
-    int *dCounts = nullptr, *dLists = nullptr;
-    const size_t lb = sizeof(int) * (size_t)c->n * (size_t)max_neighbors;
-    HIP_TRY(c, hipMalloc((void**)&dCounts, sizeof(int) * (size_t)c->n));
-    if (lists && lb) {
-        hipError_t e = hipMalloc((void**)&dLists, lb);
-        if (e != hipSuccess) { (void)hipFree(dCounts); return fail(c, SPH_E_NOMEM, "neighbour list alloc failed"); }
-        (void)hipMemsetAsync(dLists, 0xFF, lb, c->stream);   // unused tail entries read back as -1
-    }
     StateSet s = curSet(c);
-    hipLaunchKernelGGL(k_export_neighbors, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.origId,
-                       c->cellCum, c->counters, dCounts, dLists, max_neighbors);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(counts, dCounts, sizeof(int) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess && dLists) e = hipMemcpyAsync(lists, dLists, lb, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(dCounts);
-    if (dLists) (void)hipFree(dLists);
-    if (e != hipSuccess) return fail(c, SPH_E_HIP, "neighbour export failed: %s", hipGetErrorString(e));
+    return exportLists(c, counts, lists, max_neighbors, [&](int* dCounts, int* dLists) {
+        hipLaunchKernelGGL(k_export_neighbors, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->dp, s.posM, s.origId,
+                           c->cellCum, c->counters, dCounts, dLists, max_neighbors);
+    });
+}
+
+int sph_download_hit_lists(sph_ctx* c, int32_t* counts, int32_t* lists, int max_neighbors, int* mask_state) {
+    if (!c) return SPH_E_INVALID;
+    if (!counts || max_neighbors < 0 || !mask_state) return fail(c, SPH_E_INVALID, "bad hit list export arguments");
+    int rc = checkReady(c, true);
+    if (rc) return rc;
+    if (c->slab) return fail(c, SPH_E_STATE, "hit list export is indexed by id: not available in slab mode");
+    HIP_TRY(c, hipSetDevice(c->device));
+    *mask_state = 0;
+    if (!c->maskValid || !c->hitMask) return SPH_OK;          // no fresh mask: CS_ForceXSPH would take the scan kernel
+    int overflow = 0;
+    if (int rcRead = readInts(c, c->counters + SPH_CTR_BIN_OVERFLOW, 1, &overflow)) return rcRead;
+    if (overflow) { *mask_state = 2; return SPH_OK; }          // a bin overflowed: nothing was recorded, every wave scans
+    *mask_state = 1;
+    StateSet s = curSet(c);
+    return exportLists(c, counts, lists, max_neighbors, [&](int* dCounts, int* dLists) {
+        hipLaunchKernelGGL(k_export_hit_lists, dim3(blocksFor(c->n)), dim3(kBlock), 0, c->stream, c->dp, (const float4*)s.posM,
+                           (const uint32_t*)s.origId, (const int*)c->cellCum, (const uint32_t*)c->hitMask, c->capacity, dCounts,
+                           dLists, max_neighbors);
+    });
+}
+
+int sph_upload_particles_in_place(sph_ctx* c, const void* aos72, int n) {
+    if (!c) return SPH_E_INVALID;
+    if (c->slab) return fail(c, SPH_E_STATE, "id-ordered AoS transfer is not available in slab mode (use sph_slab_upload)");
+    if (!aos72) return fail(c, SPH_E_INVALID, "null particle array");
+    if (n != c->n || n <= 0) return fail(c, SPH_E_INVALID, "upload count %d != allocated %d", n, c->n);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)n * SPH_PARTICLE_BYTES;
+    int rc = ensurePinned(c, bytes);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // previous use of the staging buffers
+    memcpy(c->pinned, aos72, bytes);
+    HIP_TRY(c, hipMemcpyAsync(c->aosStage, c->pinned, bytes, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_update_aos_in_place, dim3(blocksFor(n)), dim3(kBlock), 0, c->stream, n, (const float*)c->aosStage, curSet(c),
+                       c->color);
+    CHECK_LAUNCH(c);
+    // positions, densities and velocities changed under everything derived from them; the grid is deliberately kept
+    c->maskValid = false; c->packedValid = false; c->pos3Valid = false;
+    c->staticDirty = true;   // as after sph_upload_particles: SPH.cs:284-298 rewrites the static fields on the next Update
     return SPH_OK;
 }
 

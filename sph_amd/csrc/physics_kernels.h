@@ -1023,4 +1023,62 @@ __global__ __launch_bounds__(kBlock) void k_export_neighbors(DevParams P, const 
     counts[id] = cnt;
 }
 
+// Hit-mask export (parity only): decodes what k_density_pressure_rows recorded for the force kernel -- the bit rows
+// k_force_xsph_hits walks -- into id lists in visiting order, with the decode of that kernel: row t of a particle
+// starts a fresh word, bit b of the row's k-th word is slot row.a + 32 k + b; words 0..15 live in the particle's
+// 64-byte line, words 16..23 in the second array.  counts[id] = -1: the particle has no usable mask (it needs more
+// than kMaskWords words, or a row of more than 8 words: its wave takes the scan path).
+__global__ __launch_bounds__(kBlock) void k_export_hit_lists(DevParams P, const float4* __restrict__ posM,
+                                                             const uint32_t* __restrict__ origId,
+                                                             const int* __restrict__ cellCum,
+                                                             const uint32_t* __restrict__ hitMask, int maskStride,
+                                                             int* __restrict__ counts, int* __restrict__ lists,
+                                                             int maxNeighbors) {
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= P.n) return;
+    const float4 p = posM[s];
+    const uint32_t id = origId[s];
+    const int3 c = search_cell(P, p.x, p.y, p.z);
+    RowRange rr[9];
+    int nWords = 0;
+    for (int t = 0; t < 9; t++) {
+        rr[t] = row_range(P, cellCum, c, t % 3 - 1, t / 3 - 1, true);
+        const int nw = (rr[t].e - rr[t].a + 31) >> 5;
+        nWords += nw > 8 ? kMaskWords + 1 : nw;
+    }
+    if (nWords > kMaskWords) { counts[id] = -1; return; }
+    const uint32_t* const lo = hitMask + (size_t)s * kMaskStage;
+    const uint32_t* const hi = hitMask + (size_t)maskStride * kMaskStage + (size_t)s * (kMaskWords - kMaskStage) - kMaskStage;
+    int cnt = 0, idx = 0;
+    for (int t = 0; t < 9; t++) {
+        const int nw = (rr[t].e - rr[t].a + 31) >> 5;
+        for (int k = 0; k < nw; k++, idx++) {
+            uint32_t w = idx < kMaskStage ? lo[idx] : hi[idx];
+            while (w) {
+                const int j = rr[t].a + (k << 5) + __builtin_ctz(w);
+                w &= w - 1;
+                if (cnt < maxNeighbors && lists) lists[(size_t)id * maxNeighbors + cnt] = j < P.n ? (int)origId[j] : -2;
+                cnt++;
+            }
+        }
+    }
+    counts[id] = cnt;
+}
+
+// ComputeBuffer.SetData in the MIDDLE of a frame (parity / debugging): the reference's SetData leaves GridCounts and
+// GridIndices as they are, so the records are written over the particles where they sit -- slot order and grid stay.
+__global__ __launch_bounds__(kBlock) void k_update_aos_in_place(int n, const float* __restrict__ aos, StateSet st,
+                                                                float4* __restrict__ color) {
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    const uint32_t id = st.origId[s];
+    const float* r = aos + (size_t)id * SPH_PARTICLE_FLOATS;
+    st.posM[s] = make_float4(r[0], r[1], r[2], r[13]);
+    st.velV[s] = make_float4(r[3], r[4], r[5], r[12]);
+    st.acc[s] = make_float4(r[6], r[7], r[8], 0.f);
+    st.rhoP[s] = make_float2(r[9], r[10]);
+    st.rho0[s] = r[11];
+    color[id] = make_float4(r[14], r[15], r[16], r[17]);
+}
+
 }  // namespace sph

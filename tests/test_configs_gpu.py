@@ -92,6 +92,17 @@ def test_full_size_lockstep_against_openmp_oracle(which, n):
         assert len({s["grid"] for s in stats}) >= 2, "config 3 never regridded"
 
 
+@pytest.mark.parametrize("which,n", [("config2", 262144), ("config3", 1048576)])
+def test_full_size_hit_mask_against_openmp_oracle(which, n):
+    """The same two configurations, kernel by kernel (tests.util.run_stepwise): behind CS_DensityPressure the bit mask the
+    force kernel walks is decoded on the device and held bit-exactly to the oracle's neighbour lists (compute:170-181),
+    at the size the metric is quoted on; frame 1 of config 3 runs on the regridded (rocked) cube."""
+    from tests.util import run_stepwise
+    builder = {"config2": lambda e: scenes.config2(e, n=n), "config3": lambda e: scenes.config3(e, n=n)}[which]
+    st = run_stepwise(builder, 2, tol=TOL, max_nb=224, want_overflow=False, omp=True)
+    assert st["masks"] == 2
+
+
 @pytest.mark.parametrize("which,n", [("config5", 8388608), ("config4", 16777216)])
 def test_largest_single_gpu_sizes_one_frame_against_openmp_oracle(which, n):
     """The sizes the multi-GPU configurations put on ONE GPU: config 5's per-GPU block (8,388,608 particles, 31 M cells)

@@ -115,3 +115,108 @@ def check_against_golden(engine, fx, tol, exact_fields=False, what=""):
         assert_fields_close(got, want, tol, what)
     ctr = [engine.read_counter(k) for k in range(3)]
     assert ctr == fx["counters"].tolist(), what + f"counters {ctr} != {fx['counters'].tolist()}"
+
+
+# ---- engine and oracle driven as ONE engine (kernel-granular lock-step) ---------------------------
+class Pair:
+    """Looks like one engine to sph_amd.host.SPH and forwards every call to the engine AND the oracle, so that one
+    host driver steps both through a frame kernel by kernel.  `after(kernel_id)` runs behind every dispatch: that is
+    where tests compare mid-frame artefacts (the hit mask behind CS_DensityPressure) and re-synchronise the engine to
+    the oracle between sub-steps."""
+    grid_first = False
+
+    def __init__(self, eng, ora, after=None):
+        self.eng, self.ora, self.after = eng, ora, after
+
+    @property
+    def n(self):
+        return self.eng.n
+
+    def dispatch(self, kernel_id, count=None):
+        self.eng.dispatch(kernel_id, count)
+        self.ora.dispatch(kernel_id, count)
+        if self.after:
+            self.after(kernel_id)
+
+    def download_particles(self):
+        return self.ora.download_particles()
+
+    def destroy(self):
+        self.eng.destroy()
+        self.ora.destroy()
+
+    def __getattr__(self, name):
+        if name.startswith("_") or not hasattr(self.ora, name):
+            raise AttributeError(name)
+        fe, fo = getattr(self.eng, name), getattr(self.ora, name)
+
+        def both(*a, **k):
+            r = fe(*a, **k)
+            fo(*a, **k)
+            return r
+        return both
+
+
+def assert_hit_lists_equal(eng, ora, max_nb=512, what="", expect_overflow=None):
+    """The bit mask the force kernel is about to walk, decoded (sph_download_hit_lists), against the oracle's
+    neighbour lists (compute:170-181 as the oracle restates it) -- bit-exact, in visiting order.  Returns the mask
+    state; with a bin over its capacity the engine must have recorded NO mask (state 2: the capped scan path runs)."""
+    state, ec, el = eng.download_hit_lists(max_nb)
+    overflow = ora.read_counter(abi.CTR_BIN_OVERFLOW) > 0
+    if expect_overflow is not None:
+        assert overflow == expect_overflow, what + f"oracle overflow flag is {overflow}"
+    if overflow:
+        assert state == 2, what + f"a bin overflowed but the engine reports mask state {state}"
+        return state
+    assert state == 1, what + f"no fresh hit mask behind CS_DensityPressure (state {state})"
+    oc, ol = ora.download_neighbors(max_nb)
+    assert int(oc.max(initial=0)) <= max_nb
+    have = ec >= 0                       # -1: the particle's rows need more mask words than a row holds (its wave scans)
+    assert np.all(ec[~have] == -1)
+    assert have.mean() > 0.9, what + f"only {have.mean():.2%} of the particles have a mask"
+    assert np.array_equal(ec[have], oc[have]), what + "hit counts differ from the oracle's neighbour counts"
+    assert np.array_equal(el[have], ol[have]), what + "hit lists differ from the oracle's neighbour lists"
+    return state
+
+
+def run_stepwise(builder, frames, tol=1e-5, max_nb=1024, want_overflow=None, min_masked=1, omp=False):
+    """builder(engine) -> Scene.  Returns statistics of what was checked."""
+    from oracle.ora import Oracle
+    from sph_amd import abi
+    eng, ora = abi.Engine(0), Oracle(omp=omp)
+    stats = dict(masks=0, overflow_masks=0, substeps=0)
+    where = [""]
+
+    def after(kid):
+        if kid == abi.K_DENSITY_PRESSURE:
+            state = assert_hit_lists_equal(eng, ora, max_nb, where[0] + "behind CS_DensityPressure: ")
+            stats["masks" if state == 1 else "overflow_masks"] += 1
+        elif kid == abi.K_BOUND_OBS:
+            # end of a sub-step: plain bar, then continue from the oracle's state (grid kept)
+            state = ora.download_particles()
+            assert_fields_close(eng.download_particles(), state, tol, where[0] + f"sub-step {stats['substeps']}: ")
+            eng.upload_particles_in_place(state)
+            stats["substeps"] += 1
+
+    pair = Pair(eng, ora, after)
+    sc = builder(pair)
+    sc.sph.use_step_frame = False
+    sc.start()
+    for f in range(frames):
+        where[0] = f"frame {f}: "
+        eng.upload_particles(ora.download_particles())
+        sc.frame()
+        cap = sc.sph.maxParticlesPerCell
+        assert_grid_equal(eng.download_grid(), ora.download_grid(with_counts=True), cap, where[0])
+        assert_neighbors_equal(eng, ora, max_nb, where[0])
+        assert_fields_close(eng.download_particles(), ora.download_particles(), tol, where[0])
+        for ctr in range(3):
+            assert eng.read_counter(ctr) == ora.read_counter(ctr), where[0] + f"counter {ctr}"
+    pair.destroy()
+    assert stats["masks"] + stats["overflow_masks"] == stats["substeps"] > 0
+    if want_overflow is True:
+        assert stats["overflow_masks"] > 0, "the case was meant to overflow a bin"
+    if want_overflow is False:
+        assert stats["overflow_masks"] == 0
+    assert stats["masks"] >= min_masked
+    return stats
