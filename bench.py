@@ -107,10 +107,11 @@ def pick_json_line(text):
 def self_launch(argv, n_ranks):
     rc, out = run_ranks(launch_plan(argv, n_ranks))
     line = pick_json_line(out)
+    if line is not None:
+        print(line)                 # also of a run that declared itself invalid (value null, invalid_reason): the record says why
     if rc != 0 or line is None:
         sys.stderr.write(out)
         raise SystemExit(rc or 1)
-    print(line)
     return 0
 
 

@@ -305,8 +305,9 @@ int  sph_slab_plane_counts(sph_ctx* ctx, int32_t* counts, int n_planes);
  * in a static device array of the library (SPH_PLANE_COUNTS_MAX ints = 32 KiB per GPU, held until the process ends)
  * instead of a buffer allocated on demand: the call makes no hipMalloc / hipFree.  n_planes > SPH_PLANE_COUNTS_MAX is
  * rejected (SPH_E_INVALID).  `counts` may be device memory of the ctx's GPU or host memory (pinned host memory if the
- * caller also forbids the runtime's own staging of pageable copies).  Every call on a GPU shares that GPU's array:
- * calls that overlap on one GPU (two ctxs on the same device driven from two threads) race.  Synchronises. */
+ * caller also forbids the runtime's own staging of pageable copies).  Every call on a GPU shares that GPU's array; the
+ * library serialises them (a per-device lock held for the duration of the call, which synchronises anyway), so two
+ * ctxs on one device may call it from two threads.  Synchronises. */
 #define SPH_PLANE_COUNTS_MAX 8192
 int  sph_slab_plane_counts_noalloc(sph_ctx* ctx, int32_t* counts, int n_planes);
 /* Current local particle count (owned + ghosts). */

@@ -175,6 +175,7 @@ namespace {
 // Device address of `scratch` on `device` (which must be current): resolved once per device, then cached.
 constexpr int kMaxDevices = 64;
 std::mutex g_scratchMutex;
+std::mutex g_scratchUse[kMaxDevices];      // serialises the users of one GPU's `scratch` (sph_slab_plane_counts_noalloc)
 int* g_scratchPtr[kMaxDevices] = {};
 
 hipError_t planeScratchFor(int device, int** out) {
@@ -734,10 +735,16 @@ int sph_create(sph_ctx** out, int device_id) {
         sph_destroy(c);
         return SPH_E_HIP;
     }
+    bool eventsOk = true;
     for (int r = 0; r < kTimingRing; r++)
         // no system-scope fence (cache write-back) when the event completes: it only brackets kernels on this stream
-        for (int k = 0; k < kNumEvents; k++) (void)hipEventCreateWithFlags(&c->ev[r][k], c->eventFlags);
-    (void)hipEventCreateWithFlags(&c->packEvent, hipEventDisableTiming);
+        for (int k = 0; k < kNumEvents; k++) eventsOk = eventsOk && hipEventCreateWithFlags(&c->ev[r][k], c->eventFlags) == hipSuccess;
+    eventsOk = eventsOk && hipEventCreateWithFlags(&c->packEvent, hipEventDisableTiming) == hipSuccess;
+    if (!eventsOk) {   // a context without its events would silently time nothing (and hang sph_slab_pack_wait)
+        (void)hipGetLastError();
+        sph_destroy(c);
+        return SPH_E_HIP;
+    }
     if (hipHostMalloc((void**)&c->hostInts, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void**)&c->countersBase, 2 * SPH_CTR_COUNT * sizeof(int)) != hipSuccess ||
         hipMalloc((void**)&c->slabCounts, 4 * sizeof(int)) != hipSuccess ||
@@ -1490,6 +1497,10 @@ int sph_slab_plane_counts_noalloc(sph_ctx* c, int32_t* counts, int n_planes) {
     if (!c->planeScratch) return fail(c, SPH_E_STATE, "static scratch not resolved on GPU %d", c->device);
     HIP_TRY(c, hipSetDevice(c->device));
     int* const ptr = c->planeScratch;
+    // every ctx on this GPU shares the array: one call at a time per device (the call synchronises before it returns,
+    // so holding the lock over it costs nothing)
+    if (c->device < 0 || c->device >= kMaxDevices) return fail(c, SPH_E_INVALID, "device %d out of range", c->device);
+    std::lock_guard<std::mutex> lock(g_scratchUse[c->device]);
     HIP_TRY(c, hipMemsetAsync(ptr, 0, sizeof(int) * (size_t)n_planes, c->stream));
     const long long rows = c->tableCells / c->rx;
     hipLaunchKernelGGL(k_plane_counts, dim3((unsigned)((rows + kPlaneRows - 1) / kPlaneRows)), dim3(kBlock), 0, c->stream,

@@ -92,8 +92,10 @@ class DevicePort:
         self.e = engine
         self.device = torch.device("cuda", device_index)
         self.cap = int(msg_capacity)
-        self.send_l = torch.empty((self.cap, REC), dtype=torch.uint8, device=self.device)
-        self.send_r = torch.empty((self.cap, REC), dtype=torch.uint8, device=self.device)
+        # one spare row in front of the records: the header of the face message (NeighbourComm.exchange sends
+        # header + records as ONE tensor, straight out of these buffers)
+        self.send_bases = [torch.empty((self.cap + 1, REC), dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self.send_l, self.send_r = self.send_bases[0][1:], self.send_bases[1][1:]
 
     def configure(self, rx_global, x_offset, rx_local, ry, rz, cap, own_lo, own_hi, capacity):
         self.e.slab_configure(rx_global, x_offset, own_lo, own_hi)
@@ -130,10 +132,9 @@ class DevicePort:
     def rebuild(self, keep_lo, keep_hi, from_left, from_right):
         pl = from_left.data_ptr() if from_left is not None and from_left.shape[0] else None
         pr = from_right.data_ptr() if from_right is not None and from_right.shape[0] else None
-        if pl is not None or pr is not None:
-            # received data is complete (torch's stream only: the engine's own stream may still be running the
-            # frame whose messages these are -- that is the overlap)
-            self.torch.cuda.current_stream(self.device).synchronize()
+        # (the received records are complete: NeighbourComm.exchange returned after it had read their headers on the
+        # host, behind the transfer in stream order; the engine's own stream may still be running the frame whose
+        # messages these are -- that is the overlap)
         nl = 0 if pl is None else from_left.shape[0]
         nr = 0 if pr is None else from_right.shape[0]
         return self.e.slab_rebuild(keep_lo, keep_hi, pl, nl, pr, nr)
@@ -148,9 +149,26 @@ class DevicePort:
 # ------------------------------------------------------------------------------------------------
 # communication: neighbour-to-neighbour send/recv of record tensors
 # ------------------------------------------------------------------------------------------------
+HDR_COUNT, HDR_NEED = 0, 1          # int64 fields of a message's header row (64 bytes = 8 fields)
+FIRST_BOUND = 4096                   # records both ends of a face expect in the first message (before any was seen)
+
+
+def next_bound(n: int, cap: int = 0) -> int:
+    """Records both ends of a face reserve for the NEXT message in a direction, from the size of the last one (which
+    both know): a sixteenth of headroom -- face populations change by a few per cent per frame -- so that the message
+    is one transfer of a size the receiver can post without having been told it."""
+    b = int(n) + (int(n) >> 4) + 256
+    return min(b, cap) if cap else b
+
+
 class NeighbourComm:
-    """Neighbour-to-neighbour exchange of record tensors.  Count and payload buffers are allocated once;
-    per frame there is one host synchronisation (reading the two incoming counts)."""
+    """Neighbour-to-neighbour exchange of record tensors, ONE message per face and direction per frame: a header row
+    (record count, ghost width the sender asks for) followed by the records, padded to the size both ends predicted
+    from the previous frame's message (next_bound) -- send and receive sizes must match and the receiver cannot know
+    the count before it has the message.  A message that outgrew its bound is completed by a second transfer of exactly
+    the missing records (both ends see the count in the header), which happens in the first frame and whenever a face
+    population jumps by more than a sixteenth.  Per exchange the host waits once: for the incoming headers (behind the
+    transfer in stream order, so the records are complete as well and the send buffers are free again)."""
 
     def __init__(self, rank: int, world: int, device, backend: Optional[str] = None, msg_capacity: int = 0):
         import torch
@@ -159,13 +177,13 @@ class NeighbourComm:
         self.rank, self.world, self.device = rank, world, device
         self.backend = backend or dist.get_backend()
         self.stage_cpu = self.backend == "gloo"
-        dev = self._dev()
-        # per face: [record count, ghost width the sender needs (adaptive ghost width; 0 = not in use)]
-        self.cnt_send = torch.zeros((2, 2), dtype=torch.int64, device=dev)
-        self.cnt_recv = torch.zeros((2, 2), dtype=torch.int64, device=dev)
         self.peer_need = (0, 0)          # what the left / right neighbour said it needs, as of the last exchange
-        self.cap = int(msg_capacity)
-        self.buf = [torch.empty((self.cap, REC), dtype=torch.uint8, device=dev) for _ in range(2)] if self.cap else None
+        self.cap = int(msg_capacity)     # records per message at most (0: unlimited); must be the same on every rank
+        self.bound_send = [FIRST_BOUND, FIRST_BOUND]
+        self.bound_recv = [FIRST_BOUND, FIRST_BOUND]
+        self.rbuf = [None, None]
+        self.exchanges = self.rounds = self.host_waits = 0
+        self.padded_records = self.sent_records = 0
 
     def _dev(self):
         return self.torch.device("cpu") if self.stage_cpu else self.device
@@ -177,59 +195,108 @@ class NeighbourComm:
         for t, peer in recvs:
             ops.append(self.dist.P2POp(self.dist.irecv, t, peer))
         if ops:
+            self.rounds += 1
             for w in self.dist.batch_isend_irecv(ops):
                 w.wait()
 
-    def _recv_buffer(self, side, n):
-        if self.buf is not None and n <= self.cap:
-            return self.buf[side][:n]
-        return self.torch.empty((n, REC), dtype=self.torch.uint8, device=self._dev())
-
-    def exchange(self, to_left, to_right, need=0):
-        """Send to_left to rank-1 and to_right to rank+1; returns (from_left, from_right).  `need` (an int) rides in
-        the count message to both neighbours; theirs end up in self.peer_need."""
+    def _recv_rows(self, side, rows):
+        """Receive buffer of this face, at least `rows` rows (header included); contents are kept when it grows."""
         torch = self.torch
-        left = self.rank - 1 if self.rank > 0 else None
-        right = self.rank + 1 if self.rank < self.world - 1 else None
-        if left is None and right is None:
-            return None, None
-        # 1) counts (two preallocated int64 pairs; fill_ is asynchronous, tolist() is the one sync)
-        self.cnt_send[0, 0:1].fill_(int(to_left.shape[0]))
-        self.cnt_send[1, 0:1].fill_(int(to_right.shape[0]))
-        self.cnt_send[:, 1:2].fill_(int(need))
-        self.cnt_recv.zero_()
-        sends, recvs = [], []
-        if left is not None:
-            sends.append((self.cnt_send[0], left)); recvs.append((self.cnt_recv[0], left))
-        if right is not None:
-            sends.append((self.cnt_send[1], right)); recvs.append((self.cnt_recv[1], right))
-        self._xfer(sends, recvs)
-        (n_from_l, need_l), (n_from_r, need_r) = ((int(v) for v in row) for row in self.cnt_recv.tolist())
-        self.peer_need = (need_l, need_r)
-        # 2) payload
+        cur = self.rbuf[side]
+        if cur is None or cur.shape[0] < rows:
+            want = max(rows, (self.cap + 1) if self.cap else rows + (rows >> 2))
+            new = torch.empty((want, REC), dtype=torch.uint8, device=self._dev())
+            if cur is not None:
+                new[:cur.shape[0]] = cur
+            self.rbuf[side] = cur = new
+        return cur
+
+    def _message(self, side, recs, base, bound, need):
+        """The tensor to send: header row + the first min(n, bound) records + padding up to `bound` rows.  `base`: a
+        buffer whose rows 1.. already hold the records (DevicePort.send_bases), used in place."""
+        torch = self.torch
+        n = int(recs.shape[0])
         dev = self._dev()
-        buf_l, buf_r = self._recv_buffer(0, n_from_l), self._recv_buffer(1, n_from_r)
-        sends, recvs = [], []
-        if left is not None:
-            if to_left.shape[0]:
-                sends.append((to_left.to(dev).contiguous(), left))
-            if n_from_l:
-                recvs.append((buf_l, left))
-        if right is not None:
-            if to_right.shape[0]:
-                sends.append((to_right.to(dev).contiguous(), right))
-            if n_from_r:
-                recvs.append((buf_r, right))
+        hdr = torch.zeros(REC // 8, dtype=torch.int64)
+        hdr[HDR_COUNT], hdr[HDR_NEED] = n, int(need)
+        in_place = (base is not None and base.device == dev and base.shape[0] >= bound + 1 and
+                    (n == 0 or recs.data_ptr() == base[1:].data_ptr()))
+        if in_place:
+            msg = base[:bound + 1]
+        else:
+            msg = torch.empty((bound + 1, REC), dtype=torch.uint8, device=dev)
+            k = min(n, bound)
+            if k:
+                msg[1:1 + k] = recs[:k].to(dev)
+        msg[0:1].view(torch.int64).copy_(hdr.view(1, -1))
+        return msg
+
+    def exchange(self, to_left, to_right, need=0, bases=None):
+        """Send to_left to rank-1 and to_right to rank+1; returns (from_left, from_right).  `need` (an int) rides in
+        the header to both neighbours; theirs end up in self.peer_need.  `bases`: the two buffers the records sit in
+        behind a spare header row (DevicePort.send_bases), or None."""
+        torch = self.torch
+        peers = [self.rank - 1 if self.rank > 0 else None, self.rank + 1 if self.rank < self.world - 1 else None]
+        if peers[0] is None and peers[1] is None:
+            return None, None
+        self.exchanges += 1
+        dev = self._dev()
+        out = [to_left, to_right]
+        sends, recvs, sent_first = [], [], [0, 0]
+        for k in (0, 1):
+            if peers[k] is None:
+                continue
+            bound = self.bound_send[k]
+            msg = self._message(k, out[k], None if bases is None else bases[k], bound, need)
+            sent_first[k] = min(int(out[k].shape[0]), bound)
+            self.sent_records += sent_first[k]
+            self.padded_records += bound - sent_first[k]
+            sends.append((msg, peers[k]))
+            recvs.append((self._recv_rows(k, self.bound_recv[k] + 1)[:self.bound_recv[k] + 1], peers[k]))
         self._xfer(sends, recvs)
-        if self.stage_cpu:
-            if self.device is not None and self.torch.device(self.device).type != "cpu":
-                buf_l, buf_r = buf_l.to(self.device), buf_r.to(self.device)
-        elif sends or recvs:
-            # RCCL: wait() only orders torch's stream behind the transfer.  The engine works on its own
-            # stream (it reads the received records, and next frame's pack overwrites the send buffers),
-            # so the host waits here for both directions.
-            torch.cuda.current_stream(self.device).synchronize()
-        return buf_l, buf_r
+        # the one host wait: the incoming headers (behind the transfer in stream order)
+        hdrs = torch.stack([self.rbuf[k][0] if peers[k] is not None else torch.zeros(REC, dtype=torch.uint8, device=dev)
+                            for k in (0, 1)]).cpu().view(torch.int64).reshape(2, -1)
+        self.host_waits += 1
+        n_from = [int(hdrs[k, HDR_COUNT]) if peers[k] is not None else 0 for k in (0, 1)]
+        self.peer_need = tuple(int(hdrs[k, HDR_NEED]) if peers[k] is not None else 0 for k in (0, 1))
+        if self.cap and max(n_from) > self.cap:
+            raise RuntimeError(f"incoming face message of {max(n_from)} records exceeds the message capacity {self.cap}")
+        # a message that outgrew its bound: exactly the missing records, in a second transfer
+        sends, recvs = [], []
+        for k in (0, 1):
+            if peers[k] is None:
+                continue
+            n_out = int(out[k].shape[0])
+            if n_out > sent_first[k]:
+                sends.append((out[k][sent_first[k]:].to(dev).contiguous(), peers[k]))
+                self.sent_records += n_out - sent_first[k]
+            if n_from[k] > self.bound_recv[k]:
+                buf = self._recv_rows(k, n_from[k] + 1)
+                recvs.append((buf[self.bound_recv[k] + 1:n_from[k] + 1], peers[k]))
+        if sends or recvs:
+            self._xfer(sends, recvs)
+            if not self.stage_cpu:
+                torch.cuda.current_stream(self.device).synchronize()
+                self.host_waits += 1
+        res = []
+        for k in (0, 1):
+            if peers[k] is None:
+                res.append(None)
+                continue
+            self.bound_send[k] = next_bound(int(out[k].shape[0]), self.cap)
+            self.bound_recv[k] = next_bound(n_from[k], self.cap)
+            got = self.rbuf[k][1:1 + n_from[k]]
+            if self.stage_cpu and self.device is not None and torch.device(self.device).type != "cpu":
+                got = got.to(self.device)
+            res.append(got)
+        return res[0], res[1]
+
+    def any_rank(self, flag: bool) -> bool:
+        """True on every rank if `flag` is set on any (one tiny all-reduce; not on the data path)."""
+        t = self.torch.tensor([1 if flag else 0], dtype=self.torch.int64, device=self._dev())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return bool(int(t.item()))
 
     def allreduce_sum(self, value: int) -> int:
         t = self.torch.tensor([value], dtype=self.torch.int64, device=self._dev())
@@ -317,8 +384,12 @@ class SlabEngine:
         # the frame starts: a re-cut is planned at the end of one frame (from that frame's grid), used for the send
         # range of the next frame's in-frame pack and applied at that frame's end (step_frame below)
         self._cuts_next = None
-        if self.adaptive and self.rebalance_every:
-            raise ValueError("adaptive ghost width and moving cuts are not combined yet")
+        # A particle that crosses a WHOLE neighbouring slab in one frame belongs to a rank the face messages never reach.
+        # far_guard: every frame the ranks agree (one tiny all-reduce of a flag) whether any of them measured a plane
+        # shift that large; if so the frame's owned particles are routed to their owners all-to-all (SURVEY 8e's
+        # fallback, _reroute) instead of being lost.
+        self.far_guard = True
+        self.reroutes = 0
         self.band_misses = 0
         self.band_fraction = 0.0       # share of the last force kernel that ran before the pack
         self._primed = False
@@ -434,11 +505,24 @@ class SlabEngine:
         faces = [widths[k] for k in (0, 1) if (self.rank > 0 if k == 0 else self.rank < self.world - 1)]
         if faces and 2 * self.sub_steps * (1 + shift) > min(faces):
             self.halo_violations += 1
-        # A particle that crosses a WHOLE neighbouring slab in one frame would reach a rank it is never sent to (messages
-        # go to the two face neighbours only; SURVEY 8e's all-to-all fallback is not built): stop rather than lose it.
-        if self.world > 1 and self.cuts is not None and shift >= min(b - a for a, b in zip(self.cuts[:-1], self.cuts[1:])):
-            raise RuntimeError(f"a particle moved {shift} cell planes in one frame, more than the narrowest slab is wide: "
-                               f"the run has diverged or the slabs are too narrow for it")
+            self._shifts = []                    # back to the full ghost width at once, until a new window has been seen
+
+    def _far_danger(self, shift):
+        """Could an owned particle of this rank have crossed a whole neighbouring slab (and so belong to a rank the face
+        messages do not reach)?  Necessary: a plane shift of at least that slab's width."""
+        if self.world < 3 or self.cuts is None:
+            return False                         # with two slabs every other rank IS the face neighbour
+        widths = [self.cuts[r + 1] - self.cuts[r] for r in (self.rank - 1, self.rank + 1) if 0 <= r < self.world]
+        return bool(widths) and shift >= min(widths)
+
+    def _reroute(self):
+        """SURVEY 8e's fallback for particles that jumped further than the neighbouring slab: every rank takes its owned
+        particles off the device and sends each to the rank that owns its CURRENT plane (all-to-all by searchsorted on
+        the cuts, as after a grid change); each rank starts again from its owned particles, the frame's ordinary
+        exchange supplies the ghosts.  Conserves every particle; collective."""
+        recs = self.port.download_owned()
+        self._redistribute(recs)
+        self.reroutes += 1
 
     def _adapt(self, in_flight: bool):
         """New face widths from this rank's need and the neighbours' (comm.peer_need, same frame): both ranks of a face
@@ -520,6 +604,11 @@ class SlabEngine:
         self._new_grid = None
         self._min_x, self._cell = np.float32(p.minBound[0]), np.float32(p.cellSize)
         self._set_grid(*grid)
+        self._redistribute(recs)
+        self.repartitions = getattr(self, "repartitions", 0) + 1
+
+    def _redistribute(self, recs):
+        """`recs` (this rank's owned particles) to the ranks that own their planes under the current grid and cuts."""
         rx, ry, rz, cap = self.grid
         plane = self._planes(recs["pos"][:, 0])
         dest = np.searchsorted(np.asarray(self.cuts[1:-1]), plane, side="right")
@@ -533,7 +622,6 @@ class SlabEngine:
         self.e.n = self.n
         self._primed = False          # overlap mode: the next frame gets its ghosts the classic way
         self._cuts_next = None
-        self.repartitions = getattr(self, "repartitions", 0) + 1
 
     def _distribute(self):
         rx, ry, rz, cap = self.grid
@@ -593,8 +681,12 @@ class SlabEngine:
         left_below, right_from = self._send_range()
         to_l, to_r = self.port.pack(left_below, right_from)
         if self.frames > 0 and self.world > 1:
-            self._note_shift(self.e.read_counter(abi.CTR_MAX_PLANE_SHIFT), ran_with)   # came back with pack's counts: no extra sync
-        from_l, from_r = self.comm.exchange(to_l, to_r, need=self._needed())
+            shift = self.e.read_counter(abi.CTR_MAX_PLANE_SHIFT)                       # came back with pack's counts: no extra sync
+            self._note_shift(shift, ran_with)
+            if self.far_guard and self.world > 2 and self.comm.any_rank(self._far_danger(shift)):
+                self._reroute()                     # owned particles only from here; pack again for the ghosts
+                to_l, to_r = self.port.pack(left_below, right_from)
+        from_l, from_r = self.comm.exchange(to_l, to_r, need=self._needed(), bases=getattr(self.port, "send_bases", None))
         self.n = self.port.rebuild(self.keep[0], self.keep[1], from_l, from_r)
         self.e.n = self.n
         self.exchange_s += time.perf_counter() - t0
@@ -633,12 +725,23 @@ class SlabEngine:
         t0 = time.perf_counter()
         to_l, to_r = self.port.pack_wait()          # the band part of the frame is done; the GPU carries on
         self.band_fraction = getattr(self.e, "band_workgroups", 0) / max((self.n + 255) // 256, 1)
-        self._note_shift(self.e.read_counter(abi.CTR_MAX_PLANE_SHIFT))
+        shift = self.e.read_counter(abi.CTR_MAX_PLANE_SHIFT)
+        self._note_shift(shift)
+        if self.far_guard and self.world > 2 and self.comm.any_rank(self._far_danger(shift)):
+            # some particle may belong to a rank the face messages do not reach: let the frame finish, then route every
+            # owned particle to its owner; the next frame starts the classic way (ghosts from its own exchange)
+            self.e.synchronize()
+            if self._cuts_next is not None:
+                self._apply_cuts(self._cuts_next)
+            self._reroute()
+            self.exchange_s += time.perf_counter() - t0
+            self.frames += 1
+            return
         planned = None
         if self.rebalance_every and self.frames > 0 and self.frames % self.rebalance_every == 0:
             # from THIS frame's grid (still valid: the rebuild below invalidates it), relative to the cuts about to apply
             planned = self._plan_recut(self._cuts_next or self.cuts)
-        from_l, from_r = self.comm.exchange(to_l, to_r, need=self._needed())
+        from_l, from_r = self.comm.exchange(to_l, to_r, need=self._needed(), bases=getattr(self.port, "send_bases", None))
         if self._cuts_next is not None:          # the records just received were packed for these cuts
             self._apply_cuts(self._cuts_next)
         self._cuts_next = planned
@@ -696,6 +799,7 @@ class SlabEngine:
             raise RuntimeError(f"gathered {recs.shape[0]} records for {self.n_global} particles: the slabs do not partition the ids")
         recs = recs[np.argsort(recs["id"], kind="stable")]
         aos = abi.aos_from_records(recs)
+        self.gathered_phase = recs["phase"].astype(np.uint8)       # by id: what a checkpoint of this state must hold
         rows = getattr(self, "_phases", None)
         if rows:
             colours = np.asarray([np.asarray(r[3], dtype=np.float32).reshape(4) for r in rows], dtype=np.float32)
@@ -764,7 +868,7 @@ def bench_main(args, rank, local_rank, world):
     # 5 cell planes per frame (scripts/max_shift.py), and the halo condition is ghost >= 2 (1 + shift); 2-3 planes later
     ghost = int(os.environ.get("SPH_BENCH_GHOST", "12"))
     # SPH_BENCH_ADAPTIVE_GHOST=0: keep the full ghost width for the whole run (A/B)
-    adaptive = os.environ.get("SPH_BENCH_ADAPTIVE_GHOST", "1") != "0" and not rebalance
+    adaptive = os.environ.get("SPH_BENCH_ADAPTIVE_GHOST", "1") != "0"
     se = SlabEngine(port, comm, rank, world, ghost_planes=ghost, rebalance_every=rebalance, overlap=overlap,
                     adaptive_ghost=adaptive)
     sc = scenes.config4(se, n=n_all) if strong else scenes.config5(se, gpus=world, per_gpu=per_gpu)
@@ -778,6 +882,9 @@ def bench_main(args, rank, local_rank, world):
     except abi.SphError:
         pass
     se.exchange_s = 0.0
+    warm_violations = se.halo_violations
+    se.halo_violations = 0
+    waits0, rounds0, exch0 = comm.host_waits, comm.rounds, comm.exchanges
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -793,6 +900,8 @@ def bench_main(args, rank, local_rank, world):
     tm = eng.get_timings()
     n_total = sc.sph.particleCount       # conservation is asserted by tests/test_slab_*.py
     viol = comm.allreduce_sum(se.halo_violations)
+    warm_viol = comm.allreduce_sum(warm_violations)
+    reroutes = se.reroutes
     misses = comm.allreduce_sum(se.band_misses)
     overflow = comm.allreduce_sum(eng.read_counter(abi.CTR_BIN_OVERFLOW))
     force_ms = comm.allreduce_max(tm["force_ms"])
@@ -832,6 +941,14 @@ def bench_main(args, rank, local_rank, world):
         solo_dt = comm.allreduce_max(solo_dt)
         if solo_dt != float("inf"):
             solo = per_gpu * sc.sph.subSteps * args.steps / solo_dt
+    # A timed frame whose halo was too narrow is not the single-domain computation any more, and ids that are not owned
+    # exactly once mean lost or duplicated particles: either makes the number invalid (the line says why, value is null,
+    # the exit code is non-zero).
+    invalid = None
+    if viol > 0:
+        invalid = f"{viol} halo violations in the timed frames (ghost region narrower than 2 subSteps (1 + plane shift))"
+    if conserved is False:
+        invalid = "particle ids are not owned exactly once over the ranks"
     if rank == 0:
         sub = sc.sph.subSteps
         n_local = se.n
@@ -847,7 +964,8 @@ def bench_main(args, rank, local_rank, world):
         except Exception:
             cpu = None
         print(json.dumps({
-            "metric": "particle-updates/sec", "value": n_total * sub * args.steps / dt, "unit": "particle-updates/s",
+            "metric": "particle-updates/sec", "value": None if invalid else n_total * sub * args.steps / dt,
+            "invalid_reason": invalid, "unit": "particle-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
@@ -858,7 +976,12 @@ def bench_main(args, rank, local_rank, world):
                        "particles": n_total, "sub_steps": sub, "parallelism": f"slab{world}",
                        "world_size": dist.get_world_size(), "backend": dist.get_backend(), "rehearsal": rehearsal,
                        "self_launched": os.environ.get("SPH_BENCH_SELF_LAUNCHED") == "1",
-                       "halo_violations": viol, "bin_overflow_cells": overflow, "every_id_owned_once": conserved,
+                       "halo_violations": viol, "halo_violations_warmup": warm_viol, "far_jump_reroutes": reroutes,
+                       "bin_overflow_cells": overflow, "every_id_owned_once": conserved,
+                       # blocking host waits of an overlapped frame on rank 0: the pack event, the incoming message
+                       # headers (one per exchange; + one when a message outgrew its predicted size), the survivor count
+                       "host_waits_per_frame_rank0": round(2 + (comm.host_waits - waits0) / max(args.steps, 1), 3),
+                       "transfer_rounds_per_exchange_rank0": round((comm.rounds - rounds0) / max(comm.exchanges - exch0, 1), 3),
                        "adaptive_ghost": se.adaptive, "ghost_planes_at_end": [int(widths_min), int(widths_max)],
                        "ghost_to_owned_particles_worst_rank": ghost_ratio,
                        "rebalance_every": se.rebalance_every, "recuts": se.recuts,
@@ -880,3 +1003,5 @@ def bench_main(args, rank, local_rank, world):
         }))
     eng.destroy()
     dist.destroy_process_group()
+    if invalid:
+        raise SystemExit(3)

@@ -49,7 +49,9 @@ def _phase_by_id(sph) -> np.ndarray:
     counts = [sb.particleCount for sb in sph.spawnBoxes]
     if sum(counts) == sph.particleCount and len(counts) <= 256:
         return np.repeat(np.arange(len(counts), dtype=np.uint8), counts)
-    return np.zeros(sph.particleCount, dtype=np.uint8)
+    # (all-zero phases would be accepted by load_state and give every particle phase 0's mass, viscosity and rest density)
+    raise ValueError(f"cannot derive the phase of every particle: {len(counts)} spawn boxes hold {sum(counts)} particles, "
+                     f"the run has {sph.particleCount}")
 
 
 def save_state(scene, prefix: str) -> dict:
@@ -69,7 +71,11 @@ def save_state(scene, prefix: str) -> dict:
     if aos.shape != (sph.particleCount, abi.PARTICLE_FLOATS):
         raise ValueError(f"particle buffer has shape {aos.shape}")
     aos.tofile(prefix + ".bin")
-    phase = _phase_by_id(sph)
+    # a slab run writes the phases its records actually carry (gathered with them); otherwise particleSpawnBoxIndices
+    carried = getattr(e, "gathered_phase", None) if hasattr(e, "resync") else None
+    phase = _phase_by_id(sph) if carried is None else np.ascontiguousarray(carried, dtype=np.uint8)
+    if phase.shape[0] != sph.particleCount or (phase.size and int(phase.max()) >= max(len(sph.spawnBoxes), 1)):
+        raise ValueError("phase ids do not match the particles / spawn boxes")
     np.ascontiguousarray(phase, dtype=np.uint8).tofile(prefix + ".phase")
     meta = {
         "format": FORMAT, "version": VERSION, "record_bytes": abi.PARTICLE_BYTES, "particleCount": int(sph.particleCount),

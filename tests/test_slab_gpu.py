@@ -360,3 +360,67 @@ def test_checkpoints_move_between_one_gpu_and_slabs(tmp_path, world, overlap):
             for ext in (".bin", ".phase"):
                 assert open(tmp_path / ("slab" + ext), "rb").read() == open(tmp_path / ("single" + ext), "rb").read(), ext
             assert json.load(open(tmp_path / "slab.json")) == json.loads(json.dumps(single))
+
+
+def test_one_message_protocol_on_device_buffers_in_place():
+    """NeighbourComm.exchange with DEVICE buffers and no host staging (the RCCL configuration), two ranks played by two
+    threads of this process whose transfers are copies on the GPU: the message is the send buffer itself (header row +
+    records, no copy), sizes agree on both ends without being announced, a message that outgrew its predicted size is
+    completed by exactly one more transfer, and what arrives is what was packed."""
+    import threading
+    dev = torch.device("cuda", 0)
+    cap, frames = 6000, 9
+    sizes = {0: [100, 110, 4500, 4600, 0, 30, 31, 5999, 6000], 1: [7, 3000, 3100, 3150, 3151, 0, 0, 5, 6000]}
+    box, bar, errors = {}, threading.Barrier(2), []
+
+    class LoopComm(slab.NeighbourComm):
+        def _xfer(self, sends, recvs):
+            self.rounds += 1
+            for t, peer in sends:
+                box[(self.rank, peer)] = t
+            bar.wait()
+            for t, peer in recvs:
+                src = box[(peer, self.rank)]
+                assert tuple(src.shape) == tuple(t.shape), (src.shape, t.shape)
+                assert src.device.type == "cuda" and t.device.type == "cuda"
+                t.copy_(src)
+            torch.cuda.synchronize()
+            bar.wait()
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            comm = LoopComm(rank, 2, dev, backend="nccl", msg_capacity=cap)
+            bases = [torch.zeros((cap + 1, slab.REC), dtype=torch.uint8, device=dev) for _ in range(2)]
+            side = 1 if rank == 0 else 0                       # rank 0 talks to its right neighbour, rank 1 to its left
+            g = torch.Generator(device="cpu").manual_seed(100 + rank)
+            for f in range(frames):
+                n = sizes[rank][f]
+                payload = torch.randint(0, 256, (n, slab.REC), dtype=torch.uint8, generator=g)
+                bases[side][1:1 + n] = payload.to(dev)
+                out = [bases[0][1:1], bases[1][1:1]]
+                out[side] = bases[side][1:1 + n]
+                rounds0 = comm.rounds
+                got = comm.exchange(out[0], out[1], need=10 * rank + f, bases=bases)[side]
+                # what the peer packed this frame (same generator sequence, replayed here)
+                peer = 1 - rank
+                gp = torch.Generator(device="cpu").manual_seed(100 + peer)
+                for ff in range(f + 1):
+                    want = torch.randint(0, 256, (sizes[peer][ff], slab.REC), dtype=torch.uint8, generator=gp)
+                assert got.device.type == "cuda" and got.shape[0] == sizes[peer][f]
+                assert torch.equal(got.cpu(), want), f"rank {rank} frame {f}: payload differs"
+                assert comm.peer_need[side] == 10 * peer + f
+                last = {0: slab.FIRST_BOUND, 1: slab.FIRST_BOUND} if f == 0 else \
+                    {rank: slab.next_bound(sizes[rank][f - 1], cap), peer: slab.next_bound(sizes[peer][f - 1], cap)}
+                overflow = n > last[rank] or sizes[peer][f] > last[peer]
+                assert comm.rounds - rounds0 == (2 if overflow else 1), f"rank {rank} frame {f}: {comm.rounds - rounds0} rounds"
+        except BaseException as exc:   # noqa: BLE001 - reported in the main thread
+            errors.append(exc)
+            bar.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
