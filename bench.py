@@ -212,17 +212,25 @@ def main(argv=None):
     try:
         tm = eng.get_timings()            # launch-attached events on the engine's stream, averaged over the timed frames
     except abi.SphError:                  # SPH_HIP_TIMING=0: no kernel times, the line still carries the throughput
-        tm = {k: float("nan") for k in ("build_grid_ms", "half_step_ms", "density_ms", "force_ms", "full_step_ms",
-                                        "bound_obs_ms", "damping_ms", "frame_ms")}
+        tm = {k: None for k in ("build_grid_ms", "half_step_ms", "density_ms", "force_ms", "full_step_ms",
+                                "bound_obs_ms", "damping_ms", "frame_ms")}
         tm["frames"] = 0
     overflow = eng.read_counter(abi.CTR_BIN_OVERFLOW)
     non_finite = eng.read_counter(abi.CTR_NAN)
 
     sub = sc.sph.subSteps
     value = n * sub * args.steps / dt
-    force_s = tm["force_ms"] * 1e-3
-    achieved = FORCE_BYTES_PER_PARTICLE * n / force_s / 1e9
-    dens_gbps = DENSITY_BYTES_PER_PARTICLE * n / (tm["density_ms"] * 1e-3) / 1e9
+    # without kernel times (SPH_HIP_TIMING=0) everything derived from them is null: the line stays strict JSON
+    timed = bool(tm["frames"]) and tm["force_ms"] and tm["density_ms"]
+    achieved = FORCE_BYTES_PER_PARTICLE * n / (tm["force_ms"] * 1e-3) / 1e9 if timed else None
+    dens_gbps = DENSITY_BYTES_PER_PARTICLE * n / (tm["density_ms"] * 1e-3) / 1e9 if timed else None
+    frac = (lambda g: None if g is None else g / HBM_PEAK_GBPS)
+    # what `traffic` counts: FETCH_SIZE / WRITE_SIZE are the L2's fabric-side requests; Infinity-Cache hits are in them
+    # (MI355X_MICROARCH.md, HBM section), and a state of ~150 B per particle fits the 256 MiB Infinity Cache up to ~1.5 M
+    # particles -- there `traffic` is L2-miss traffic (an upper bound of HBM traffic), beyond it it is HBM traffic
+    traffic_is = ("L2-miss (fabric-side) bytes per launch, Infinity-Cache hits included: the state fits the 256 MiB Infinity Cache, "
+                  "so this is an upper bound of the HBM traffic" if n * 150 < 200e6 else
+                  "L2-miss (fabric-side) bytes per launch = HBM traffic (the state does not fit the Infinity Cache)")
     run = counter_run(wl, n, args.warmup)
     result = {
         "metric": "particle-updates/sec",
@@ -244,24 +252,24 @@ def main(argv=None):
                    "frames_with_kernel_events": tm["frames"]},
         "roofline": {"bound": "hbm", "measured_limiter": MEASURED_LIMITER,
                      "kernel": "k_force_xsph_hits (CS_ForceXSPH)", "achieved": achieved,
-                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": measured_traffic(run, "k_force_xsph_hits"),
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": frac(achieved),
+                     "traffic": measured_traffic(run, "k_force_xsph_hits"), "traffic_is": traffic_is,
                      "traffic_from": None if run is None else f"warmup {run['warmup']}, steps {run['steps']} ({run.get('source', 'profiles/')})",
                      "alg_bytes_per_particle": FORCE_BYTES_PER_PARTICLE, "avg_launch_ms": tm["force_ms"],
                      "valu_issue": valu_issue(run, "k_force_xsph_hits", tm["force_ms"]),
                      "ta_busy_frac": ta_busy_frac(run, "k_force_xsph_hits", tm["force_ms"]),
-                     "density_kernel": {"achieved": dens_gbps, "frac": dens_gbps / HBM_PEAK_GBPS,
+                     "density_kernel": {"achieved": dens_gbps, "frac": frac(dens_gbps),
                                         "alg_bytes_per_particle": DENSITY_BYTES_PER_PARTICLE,
                                         "avg_launch_ms": tm["density_ms"],
                                         "traffic": measured_traffic(run, "k_density_pressure_rows"),
                                         "valu_issue": valu_issue(run, "k_density_pressure_rows", tm["density_ms"]),
                                         "ta_busy_frac": ta_busy_frac(run, "k_density_pressure_rows", tm["density_ms"])}},
-        "stage_ms": {k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")},
+        "stage_ms": {k: (None if v is None else round(v, 4)) for k, v in tm.items() if k.endswith("_ms")},
     }
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(builder, start_state, args.warmup)
     eng.destroy()
-    print(json.dumps(result))
+    print(json.dumps(result, allow_nan=False))
     return 0
 
 

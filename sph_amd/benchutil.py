@@ -42,6 +42,8 @@ def valu_issue(run, kernel, launch_ms, path=TRAFFIC_FILE):
     try:
         pk = json.load(open(path))["valu_issue_peak"]
         insts = run["kernels"][kernel]["SQ_INSTS_VALU"]
+        if not launch_ms:
+            return None
         peak = pk["wave_insts_per_s_per_simd"] * pk["simds"] / 1e9
         ach = insts / (launch_ms * 1e-3) / 1e9
         return {"wave_insts_per_launch": insts, "achieved": ach, "peak": peak, "unit": "G wave-inst/s", "frac": ach / peak,
@@ -50,9 +52,16 @@ def valu_issue(run, kernel, launch_ms, path=TRAFFIC_FILE):
         return None
 
 
-def ta_busy_frac(run, kernel, launch_ms, cus=256, clock_ghz=2.4):
+def ta_busy_frac(run, kernel, launch_ms=None, cus=256):
+    """Share of the kernel's time the texture addressers were busy, from ONE counter run: TA_TA_BUSY_sum (busy cycles
+    summed over the CUs) / CUs, over the kernel's own cycles GRBM_GUI_ACTIVE / 8 of that same run (rocprofv3 sums the
+    counter over the 8 XCDs).  No assumed clock, no launch time of another run.  Runs collected before round 3 carry no
+    GRBM_GUI_ACTIVE: for those the old estimate (this run's launch time at a nominal 2.4 GHz) is returned."""
     try:
-        busy = run["kernels"][kernel]["TA_TA_BUSY_sum"]
-        return busy / cus / (clock_ghz * 1e9) / (launch_ms * 1e-3)
+        k = run["kernels"][kernel]
+        busy = k["TA_TA_BUSY_sum"] / cus
+        if "GRBM_GUI_ACTIVE" in k:
+            return busy / (k["GRBM_GUI_ACTIVE"] / 8.0)
+        return busy / (2.4e9 * launch_ms * 1e-3)
     except Exception:
         return None

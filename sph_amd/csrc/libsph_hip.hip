@@ -54,6 +54,12 @@ struct sph_ctx {
     int cur = 0;          // set[cur] holds acc/rhoP/rho0/origId; velCur picks velV, posCur picks posM
     int velCur = 0;
     int posCur = 0;       // (the force kernel with the fused tail writes the new positions into the other buffer)
+    // SPH_HIP_LDS_DENSITY=1: CS_DensityPressure stages its candidates in LDS per workgroup (k_density_pressure_lds).
+    // Off by default: correct (bit-identical, 99.8 % of the lane-steps served from LDS, 5x fewer vector loads) but
+    // 1.7-1.9x SLOWER at 1 M particles -- 3 waves per SIMD (50 KB of LDS per workgroup) and two workgroup barriers per
+    // step leave the waves waiting 56 % of their cycles (profiles/r3_lds_density/)
+    bool ldsDensity = false;
+    unsigned long long* ldsStats = nullptr;   // SPH_HIP_LDS_STATS=1: [0] lane-steps from LDS, [1] from memory, [2] chunks staged
     bool fuseTailOk = true;   // SPH_HIP_FUSE_TAIL=0: sph_step_frame keeps the separate tail pass (A/B)
     bool tailFusedLast = false;   // the last CS_ForceXSPH launch applied the frame's tail itself
     float4* color = nullptr;       // by id
@@ -560,7 +566,17 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
             uint32_t* const mask = c->useHitMask ? c->hitMask : (uint32_t*)nullptr;
             const uint32_t* const skeys = c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr;
             const int d0 = c->tevSub ? E_DENS0 : -1, d1 = c->tevSub ? E_DENS1 : -1;
-            if (uniform)
+            if (uniform && !c->slab && c->ldsDensity && mask) {
+                // candidates staged in LDS per workgroup (k_density_pressure_lds): opt-in experiment, SPH_HIP_LDS_DENSITY=1
+                if (c->ldsStats)
+                    LAUNCH_T(c, d0, d1, k_density_pressure_lds<true>, dim3(nb), c->dp, (const float4*)s.posM, (const float*)s.rho0, s.rhoP,
+                             (const int*)c->cellCum, (const int*)c->counters, mask, c->capacity, nbr, (const float*)c->pos3,
+                             c->phaseTable[0].mass, LdsStats{c->ldsStats});
+                else
+                    LAUNCH_T(c, d0, d1, k_density_pressure_lds<false>, dim3(nb), c->dp, (const float4*)s.posM, (const float*)s.rho0, s.rhoP,
+                             (const int*)c->cellCum, (const int*)c->counters, mask, c->capacity, nbr, (const float*)c->pos3,
+                             c->phaseTable[0].mass, LdsStats{nullptr});
+            } else if (uniform)
                 LAUNCH_T(c, d0, d1, k_density_pressure_rows<true>, dim3(nb), c->dp, (const float4*)s.posM, (const float*)s.rho0, s.rhoP,
                          (const int*)c->cellCum, (const int*)c->counters, mask, c->capacity, nbr, skeys, c->blockInts,
                          (const float*)c->pos3, c->phaseTable[0].mass);
@@ -725,6 +741,7 @@ int sph_create(sph_ctx** out, int device_id) {
     if (const char* um = getenv("SPH_HIP_UNIFORM_MASS")) c->uniformMassOk = atoi(um) != 0;
     if (const char* up = getenv("SPH_HIP_UNIFORM_PHASE")) c->uniformPhaseOk = atoi(up) != 0;
     if (const char* ft = getenv("SPH_HIP_FUSE_TAIL")) c->fuseTailOk = atoi(ft) != 0;
+    if (const char* ld = getenv("SPH_HIP_LDS_DENSITY")) c->ldsDensity = atoi(ld) != 0;
     if (const char* gf = getenv("SPH_HIP_GHOST_FORCE")) c->skipGhostForce = atoi(gf) == 0;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
@@ -755,6 +772,12 @@ int sph_create(sph_ctx** out, int device_id) {
         return SPH_E_NOMEM;
     }
     c->counters = c->countersBase;
+    if (const char* ls = getenv("SPH_HIP_LDS_STATS"))
+        if (atoi(ls) != 0 && (hipMalloc((void**)&c->ldsStats, 4 * sizeof(unsigned long long)) != hipSuccess ||
+                              hipMemsetAsync(c->ldsStats, 0, 4 * sizeof(unsigned long long), c->stream) != hipSuccess)) {
+            sph_destroy(c);
+            return SPH_E_NOMEM;
+        }
     *out = c;
     return SPH_OK;
 }
@@ -765,6 +788,13 @@ int sph_destroy(sph_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     freeParticles(c);
     freeGrid(c);
+    if (c->ldsStats) {   // debug statistics of the LDS density kernel
+        unsigned long long h[4] = {0, 0, 0, 0};
+        if (hipMemcpy(h, c->ldsStats, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "[libsph_hip] k_density_pressure_lds: lane-steps from LDS %llu, from memory %llu (%.3f %%), chunks staged %llu\n",
+                    h[0], h[1], 100.0 * (double)h[1] / (double)(h[0] + h[1] + 1), h[2]);
+        devFree(c->ldsStats);
+    }
     devFree(c->countersBase);
     c->counters = nullptr;
     if (c->hostInts) (void)hipHostFree(c->hostInts);

@@ -123,16 +123,17 @@ struct PhaseConsts { float m0, m1, m2, m3, v0, v1, v2, v3; };   // named, not ar
 // records (with the survivor count of the grid build).
 struct __attribute__((packed, aligned(4))) Float4U { float x, y, z, w; };   // 16-byte load from a 4-byte aligned address
 template <bool UNIFORM_MASS>
-__global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, const float4* __restrict__ posM,
-                                                                  const float* __restrict__ rho0,
-                                                                  float2* __restrict__ rhoP,
-                                                                  const int* __restrict__ cellCum,
-                                                                  const int* __restrict__ counters,
-                                                                  uint32_t* __restrict__ hitMask, int maskStride,
-                                                                  PackedNbr nbr,
-                                                                  const uint32_t* __restrict__ slabKeys,
-                                                                  int* __restrict__ slabShift,
-                                                                  const float* __restrict__ pos3, float uniformMass) {
+__device__ __forceinline__ void density_rows_body(const DevParams& P, const float4* __restrict__ posM,
+                                                  const float* __restrict__ rho0,
+                                                  float2* __restrict__ rhoP,
+                                                  const int* __restrict__ cellCum,
+                                                  const int* __restrict__ counters,
+                                                  uint32_t* __restrict__ hitMask, int maskStride,
+                                                  const PackedNbr& nbr,
+                                                  const uint32_t* __restrict__ slabKeys,
+                                                  int* __restrict__ slabShift,
+                                                  const float* __restrict__ pos3, float uniformMass,
+                                                  uint32_t (*maskStage)[kBlock]) {
     const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
     const int nRanges = capped ? 27 : 9;
     const int s = xcd_tile(blockIdx.x, gridDim.x, P.xcdRun) * kBlock + threadIdx.x;
@@ -168,8 +169,7 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
     // need more words simply stop recording (the force kernel recomputes the word count from the
     // same ranges and falls back to scanning).  Words are staged in LDS and written out once at
     // the end, 16 bytes at a time: word-by-word global stores left every particle's line
-    // half-written in L2 for the whole kernel and cost 150 B of HBM writes per particle.
-    __shared__ uint32_t maskStage[kMaskStage][kBlock];
+    // half-written in L2 for the whole kernel and cost 150 B of HBM writes per particle.  (maskStage: LDS of the kernel.)
     // words 0..15 of a particle live in one 64-byte line; the rest (crowded particles only) in a second array
     uint32_t* const mrowG = hitMask ? hitMask + (size_t)s * kMaskStage : nullptr;
     uint32_t* const mrowHi = hitMask ? hitMask + (size_t)maskStride * kMaskStage + (size_t)s * (kMaskWords - kMaskStage) - kMaskStage : nullptr;
@@ -284,6 +284,266 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
     rhoP[s] = make_float2(density, pressure);
     if (recording && nbr.a) {
         // see PackedNbr: the phase id rides in the sign bits of density (> 0) and pressure (>= 0)
+        nbr.a[s] = make_float4(p.x, p.y, p.z, __uint_as_float(__float_as_uint(density) | ((ph & 1u) << 31)));
+        nbr.b[s] = make_float4(v.x, v.y, v.z, __uint_as_float(__float_as_uint(pressure) | ((ph & 2u) << 30)));
+    }
+}
+
+template <bool UNIFORM_MASS>
+__global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, const float4* __restrict__ posM,
+                                                                  const float* __restrict__ rho0,
+                                                                  float2* __restrict__ rhoP,
+                                                                  const int* __restrict__ cellCum,
+                                                                  const int* __restrict__ counters,
+                                                                  uint32_t* __restrict__ hitMask, int maskStride,
+                                                                  PackedNbr nbr,
+                                                                  const uint32_t* __restrict__ slabKeys,
+                                                                  int* __restrict__ slabShift,
+                                                                  const float* __restrict__ pos3, float uniformMass) {
+    __shared__ uint32_t maskStage[kMaskStage][kBlock];
+    density_rows_body<UNIFORM_MASS>(P, posM, rho0, rhoP, cellCum, counters, hitMask, maskStride, nbr, slabKeys, slabShift, pos3,
+                                    uniformMass, maskStage);
+}
+
+// CS_DensityPressure with the candidates staged in LDS per WORKGROUP (round 3; the gather this replaces is
+// compute:170-175).  The rows kernel above loads every candidate per lane: lanes of one cell load the same slots and
+// neighbouring cells' ranges overlap in two of three cells, so a workgroup pulls each candidate position through the
+// texture addresser ~7 times, and the addresser is what bounds the kernel.  Here the 256 lanes of a workgroup stage,
+// for every one of the nine (dy, dz) steps, the union of what they need -- for each distinct CURRENT (y, z) row of
+// the workgroup's particles the window [cells xmin-1 .. xmax+1] of the row (y+dy, z+dz) -- with coalesced 64-slot
+// loads into LDS, and every lane walks its own range [a, e) from there: same candidates, same order, same
+// arithmetic as the rows kernel, so the density stays bit-identical and the hit mask is the same.
+//   * The grid is STALE (bins are frame-start positions, the search cell is the current one): the lanes of a
+//     workgroup sit in ~9 distinct current rows (up to 40), not one.  Rows are keyed by their offset (-8..7)^2 from
+//     the row of the workgroup's first particle; a lane further away, or a window that no longer fits the LDS
+//     budget, simply takes the global loads of the rows kernel for that step (second pass; rare).
+//   * Windows are placed by an LDS bump allocator (order irrelevant), 64 slots per chunk; kWinChunks chunks of
+//     12-byte positions per step.
+constexpr int kWinChunks = 36;                   // 2,304 slots x 12 B = 27 KB of candidate positions per step
+constexpr int kWinSlots = kWinChunks * 64;
+constexpr int kEntSide = 16;                     // row offsets -8 .. 7 in y and z
+struct LdsStats { unsigned long long* v; };      // [0] lane-steps walked from LDS, [1] from global, [2] chunks staged (debug builds)
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_density_pressure_lds(DevParams P, const float4* __restrict__ posM,
+                                                                 const float* __restrict__ rho0,
+                                                                 float2* __restrict__ rhoP,
+                                                                 const int* __restrict__ cellCum,
+                                                                 const int* __restrict__ counters,
+                                                                 uint32_t* __restrict__ hitMask, int maskStride,
+                                                                 PackedNbr nbr, const float* __restrict__ pos3,
+                                                                 float uniformMass, LdsStats stats) {
+    __shared__ uint32_t maskStage[kMaskStage][kBlock];
+    // candidate positions, one array per coordinate, and slot j of a window at an index == j (mod 4): a lane reads the
+    // four candidates of a group as three aligned 16-byte LDS loads (ds_read_b128, 256 B/clk; 12-byte records read
+    // as dwords made the kernel LDS-bound: 0.26 ms)
+    __shared__ __attribute__((aligned(16))) float winX[kWinSlots + 4], winY[kWinSlots + 4], winZ[kWinSlots + 4];
+    __shared__ int entMin[kEntSide * kEntSide], entMax[kEntSide * kEntSide];
+    __shared__ int entA[2][kEntSide * kEntSide], entLen[2][kEntSide * kEntSide], entBase[2][kEntSide * kEntSide];
+    __shared__ int chunkDesc[2][kWinChunks];
+    __shared__ int bump[2];
+    __shared__ int ref[2];
+    if (counters[SPH_CTR_BIN_OVERFLOW] != 0) {
+        // a bin overflowed its capacity at the last grid build (rule O2): 27 capped cell ranges, no mask -- the rows kernel
+        density_rows_body<true>(P, posM, rho0, rhoP, cellCum, counters, hitMask, maskStride, nbr, nullptr, nullptr, pos3,
+                                uniformMass, maskStage);
+        return;
+    }
+    const int tid = threadIdx.x;
+    const int s = xcd_tile(blockIdx.x, gridDim.x, P.xcdRun) * kBlock + tid;
+    const bool valid = s < P.n;
+    const float4 p = posM[valid ? s : 0];
+    const uint32_t ph = (!nbr.a || !valid) ? 0u : nbr.phaseOfSlot ? nbr.phaseOfSlot[s] : nbr.phaseOfId[nbr.origId[s]];
+    const float4 v = (nbr.a && valid) ? nbr.velV[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int3 c = search_cell(P, p.x, p.y, p.z);
+    // the row table: keyed by the offset from the current row of the workgroup's first particle
+    if (tid == 0) { ref[0] = c.y; ref[1] = c.z; bump[0] = 0; bump[1] = 0; }
+    entMin[tid] = 0x7FFFFFFF;
+    entMax[tid] = -0x7FFFFFFF;
+    __syncthreads();
+    const int y0 = ref[0], z0 = ref[1];
+    const int oy = c.y - y0 + kEntSide / 2, oz = c.z - z0 + kEntSide / 2;
+    const bool regular = valid && oy >= 0 && oy < kEntSide && oz >= 0 && oz < kEntSide;
+    const int ent = regular ? oy + kEntSide * oz : 0;
+    if (regular) { atomicMin(&entMin[ent], c.x); atomicMax(&entMax[ent], c.x); }
+    __syncthreads();
+    // this thread as the OWNER of table entry `tid`
+    const int ex0 = entMin[tid], ex1 = entMax[tid];
+    const bool used = ex0 <= ex1;
+    const int ey = y0 + (tid & (kEntSide - 1)) - kEntSide / 2, ez = z0 + (tid / kEntSide) - kEntSide / 2;
+    const int wxlo = max(max(ex0 - 1, 0) - P.xoff, 0), wxhi = min(min(ex1 + 1, P.rxg - 1) - P.xoff, P.rx - 1);
+    auto window_of = [&](int t, int& A, int& len) {          // the entry's window in step t: first slot (multiple of 4), length
+        A = 0; len = 0;
+        const int y = ey + (t % 3 - 1), z = ez + (t / 3 - 1);
+        if (used && t < 9 && y >= 0 && y < P.ry && z >= 0 && z < P.rz && wxlo <= wxhi) {
+            const int base = P.rx * row_index(P.ryT, y, z);
+            A = cellCum[base + wxlo] & ~3;
+            len = cellCum[base + wxhi + 1] - A;
+        }
+    };
+    // entry owner: reserve chunks for the window, publish it (double-buffered by step parity)
+    auto publish = [&](int t, int A, int len) {
+        const int par = t & 1;
+        int chunks = (len + 63) >> 6, cb = 0;
+        if (chunks > 0) {
+            cb = atomicAdd(&bump[par], chunks);
+            if (cb + chunks > kWinChunks) {                  // does not fit: its lanes take the global loads
+                for (int i = cb; i < min(cb + chunks, kWinChunks); i++) chunkDesc[par][i] = -1;
+                chunks = 0; len = 0;
+            }
+            for (int i = 0; i < chunks; i++) chunkDesc[par][cb + i] = A + (i << 6);
+        }
+        entA[par][tid] = A; entLen[par][tid] = len; entBase[par][tid] = cb << 6;
+    };
+    float density = 0.0f;
+    uint32_t* const mrowG = hitMask ? hitMask + (size_t)s * kMaskStage : nullptr;
+    uint32_t* const mrowHi = hitMask ? hitMask + (size_t)maskStride * kMaskStage + (size_t)s * (kMaskWords - kMaskStage) - kMaskStage : nullptr;
+    const bool recording = hitMask != nullptr && valid;
+    int sh = 0, wi = 0;
+    const int maxSlot = P.n - 1 + kSlotPad;
+    RowRange r = row_range(P, cellCum, c, -1, -1, valid);
+    {
+        int A, len;
+        window_of(0, A, len);
+        publish(0, A, len);
+    }
+    // One row's walk from LDS (li = index of slot ja & ~3 in the window arrays) or from memory.  Groups are aligned to
+    // multiples of four SLOTS (that is what makes the LDS loads 16-byte aligned), so the first group of a row may start
+    // up to three slots before the row: those candidates are rejected (they add +0.0f like every rejected candidate,
+    // the sum is unchanged) and their bits are shifted out, so the mask keeps the rows kernel's layout: bit b of a
+    // row's k-th word = slot row.a + 32 k + b.
+    unsigned long long mbits = 0;
+    auto flush = [&]() {
+        if (wi < kMaskStage) maskStage[wi][tid] = (uint32_t)mbits;
+        else if (wi < kMaskWords) mrowHi[wi] = (uint32_t)mbits;
+        wi++;
+        mbits >>= 32;
+        sh -= 32;
+    };
+    auto walk_row = [&](auto ldsTag, auto selfTag, int ja, int je, int li) {
+        constexpr bool LDS = decltype(ldsTag)::value;
+        constexpr bool SELF = decltype(selfTag)::value;
+        const int last = je - 1;
+        int skip = ja & 3;
+        for (int j = ja & ~3; j < je; j += 4, li += 4) {
+            float4 qx, qy, qz;
+            if (LDS) {
+                const int q4 = li >> 2;                       // li is a multiple of 4
+                qx = ((const float4*)winX)[q4]; qy = ((const float4*)winY)[q4]; qz = ((const float4*)winZ)[q4];
+            } else {
+                const float4* const tb = (const float4*)((const char*)pos3 + (uint32_t)j * 12u);    // 48-byte aligned
+                const float4 c0 = tb[0], c1 = tb[1], c2 = tb[2];
+                qx = make_float4(c0.x, c0.w, c1.z, c2.y); qy = make_float4(c0.y, c1.x, c1.w, c2.z); qz = make_float4(c0.z, c1.y, c2.x, c2.w);
+            }
+            const float rs0 = dist2_exact(p.x - qx.x, p.y - qy.x, p.z - qz.x);
+            const float rs1 = dist2_exact(p.x - qx.y, p.y - qy.y, p.z - qz.y);
+            const float rs2 = dist2_exact(p.x - qx.z, p.y - qy.z, p.z - qz.z);
+            const float rs3 = dist2_exact(p.x - qx.w, p.y - qy.w, p.z - qz.w);
+            const float d0 = P.h2 - rs0, d1 = P.h2 - rs1, d2 = P.h2 - rs2, d3 = P.h2 - rs3;
+            const float t0 = uniformMass * P.poly6 * d0 * d0 * d0;       // compute:180, left to right
+            const float t1 = uniformMass * P.poly6 * d1 * d1 * d1;
+            const float t2 = uniformMass * P.poly6 * d2 * d2 * d2;
+            const float t3 = uniformMass * P.poly6 * d3 * d3 * d3;
+            const bool k0 = j >= ja && j <= last && rs0 < P.h2 && (!SELF || j != s);
+            const bool k1 = j + 1 >= ja && j + 1 <= last && rs1 < P.h2 && (!SELF || j + 1 != s);
+            const bool k2 = j + 2 >= ja && j + 2 <= last && rs2 < P.h2 && (!SELF || j + 2 != s);
+            const bool k3 = j + 3 <= last && rs3 < P.h2 && (!SELF || j + 3 != s);
+            density += k0 ? t0 : 0.0f;
+            density += k1 ? t1 : 0.0f;
+            density += k2 ? t2 : 0.0f;
+            density += k3 ? t3 : 0.0f;
+            const uint32_t h0 = k0, h1 = k1, h2 = k2, h3 = k3;
+            if (recording) {
+                mbits |= (unsigned long long)((h0 | (h1 << 1) | (h2 << 2) | (h3 << 3)) >> skip) << sh;
+                sh += 4 - skip;
+                if (sh >= 32) flush();
+            }
+            skip = 0;
+        }
+    };
+#pragma unroll 1
+    for (int t = 0; t < 9; t++) {
+        const int par = t & 1;
+        __syncthreads();                       // step t's windows are published; everybody is done with step t-1's LDS
+        // stage: wave w takes chunks w, w+4, ...; lane l loads slot d + l (coalesced 12-byte loads)
+        {
+            const int nCh = min(bump[par], kWinChunks);
+            const int lane = tid & 63;
+            for (int ci = tid >> 6; ci < nCh; ci += kBlock / 64) {
+                const int d = chunkDesc[par][ci];
+                if (d >= 0) {
+                    const int slot = min(d + lane, maxSlot);
+                    const float* const src = pos3 + 3 * (size_t)slot;
+                    const float x = src[0], y = src[1], z = src[2];
+                    const int di = (ci << 6) + lane;
+                    winX[di] = x; winY[di] = y; winZ[di] = z;
+                }
+            }
+            if (STATS && tid == 0) atomicAdd(&stats.v[2], (unsigned long long)nCh);
+        }
+        // meanwhile: next step's range of this lane and window of this entry (loads in flight across the walk)
+        const RowRange nxt = row_range(P, cellCum, c, (t + 1) % 3 - 1, (t + 1) / 3 - 1, valid && t + 1 < 9);
+        int nA, nLen;
+        window_of(t + 1, nA, nLen);
+        if (tid == 0) bump[par ^ 1] = 0;       // (nobody reads bump[par ^ 1] between the barrier above and the publish below)
+        __syncthreads();                       // staged
+        const int wA = entA[par][ent], wLen = entLen[par][ent], wBase = entBase[par][ent];
+        const bool nonEmpty = r.a < r.e;
+        const bool covered = nonEmpty && regular && r.a >= wA && r.e <= wA + wLen;
+        const bool self = __any(s >= r.a && s < r.e);
+        const int wiRow = wi;
+        {
+            const int ja = covered ? r.a : 0, je = covered ? r.e : 0;
+            const int li = wBase + ((r.a & ~3) - wA);          // wA, wBase are multiples of 4: so is li
+            if (self) walk_row(std::true_type{}, std::true_type{}, ja, je, li);
+            else walk_row(std::true_type{}, std::false_type{}, ja, je, li);
+        }
+        if (__any(nonEmpty && !covered)) {     // lanes outside the table / windows that did not fit: the rows kernel's loads
+            const int ja = covered ? 0 : r.a, je = covered ? 0 : r.e;
+            if (self) walk_row(std::false_type{}, std::true_type{}, ja, je, 0);
+            else walk_row(std::false_type{}, std::false_type{}, ja, je, 0);
+        }
+        if (STATS) {
+            const unsigned long long mc = __ballot(covered), mu = __ballot(nonEmpty && !covered);
+            if ((tid & 63) == 0) { atomicAdd(&stats.v[0], (unsigned long long)__popcll(mc)); atomicAdd(&stats.v[1], (unsigned long long)__popcll(mu)); }
+        }
+        if (recording) {                       // rows are padded to whole words (bits left over that lie past the row's
+            if (sh != 0 && 32 * (wi - wiRow) < r.e - r.a) flush();      // end -- alignment padding -- are not a word)
+            mbits = 0;
+            sh = 0;
+        }
+        if (t + 1 < 9) publish(t + 1, nA, nLen);
+        r = nxt;
+    }
+    if (hitMask) {
+        static_assert(kMaskStage == 16, "a mask row is four 16-byte quads");
+        const int tile = s - tid;
+        if (tile + kBlock <= P.n) {
+            __syncthreads();
+            const int lane = tid & 63, wbase = tid & ~63;
+            uint4* const wrow = (uint4*)(hitMask + (size_t)(tile + wbase) * kMaskStage);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int e = lane + 64 * k, col = wbase + (e >> 2), q4 = (e & 3) * 4;
+                wrow[e] = make_uint4(maskStage[q4][col], maskStage[q4 + 1][col], maskStage[q4 + 2][col], maskStage[q4 + 3][col]);
+            }
+        } else if (valid) {
+            const int nWords = min(wi, kMaskStage);
+            uint4* const row = (uint4*)mrowG;
+#pragma unroll
+            for (int q = 0; q < kMaskStage / 4; q++)
+                if (q * 4 < nWords)
+                    row[q] = make_uint4(maskStage[q * 4][tid], maskStage[q * 4 + 1][tid],
+                                        maskStage[q * 4 + 2][tid], maskStage[q * 4 + 3][tid]);
+        }
+    }
+    if (!valid) return;
+    const float r0 = rho0[s];
+    density = fmaxf(density, r0);                                          // compute:186
+    const float localB = r0 * (P.soundSpeed * P.soundSpeed) / P.gamma;     // compute:189
+    const float pressure = localB * (powf(density / r0, P.gamma) - 1.0f);  // compute:190
+    rhoP[s] = make_float2(density, pressure);
+    if (hitMask && nbr.a) {
         nbr.a[s] = make_float4(p.x, p.y, p.z, __uint_as_float(__float_as_uint(density) | ((ph & 1u) << 31)));
         nbr.b[s] = make_float4(v.x, v.y, v.z, __uint_as_float(__float_as_uint(pressure) | ((ph & 2u) << 30)));
     }

@@ -8,8 +8,8 @@ from .host import (SPH, CircularMotion, RockingMotion, Scene, SpawnBox, SphereCo
 
 WATER = (0.2, 0.5, 1.0, 0.8)                   # the BASELINE configurations (build-defined scenes)
 OIL = (1.0, 0.8, 0.2, 0.8)
-# SpawnBox.particleColor as serialized in the reference's scenes (Scene1.unity:306, Scene2.unity:316/411,
-# Scene3.unity:306, Scene4.unity:499/594; tests/golden/unity_scene_values.json holds every serialized value)
+# SpawnBox.particleColor as serialized in the reference's scenes (Scene1.unity:543, Scene2.unity:499/594,
+# Scene3.unity:543, Scene4.unity:499/594; tests/golden/unity_scene_values.json holds every serialized value)
 SCENE_BLUE = {1: (0.0039215684, 0.18861637, 1.0, 1.0), 2: (0.0039215684, 0.30632228, 1.0, 1.0),
               3: (0.0039215684, 0.21572512, 1.0, 1.0), 4: (0.0039215684, 0.23613732, 1.0, 1.0)}
 SCENE_YELLOW = (1.0, 0.94675124, 0.0, 1.0)
