@@ -23,17 +23,52 @@ def aggregates(P):
     }
 
 
+RHO_BINS = np.linspace(1.0, 2.0, 11)
+
+
+def rho_histogram(P):
+    """Share of the particles per bin of rho / rho0 (10 bins over [1, 2]; the density floor puts free particles at 1)."""
+    return np.histogram(np.clip(P[:, 9] / P[:, 11], 1.0, 2.0 - 1e-9), bins=RHO_BINS)[0] / len(P)
+
+
 def test_config1_1000_frames_bounded_drift():
+    """Bounded drift, quantitatively: next to the engine and the oracle a THIRD run -- the oracle again, started with
+    every position one ulp off -- measures how far two runs of this chaotic system drift apart by themselves.  Every
+    50 frames the engine may differ from the oracle, in the vertical centre of mass, in the density histogram (10 bins
+    of rho / rho0, L1 distance) by at most 3 x the largest distance the two ORACLE runs have shown up to that frame (+ a
+    small floor for the first frames, where the twins still coincide), and in the kinetic energy by at most 8 x (one
+    twin is one sample of the chaos, and the kinetic energy of the sloshing tank is its noisiest aggregate: 4.4 %
+    engine-oracle against 0.7 % oracle-twin at frame 350, 4.6 % against 5.5 % at frame 400).  Measured on
+    MI355X (scripts/freerun_probe2.py): engine-oracle and oracle-oracle spreads are the same size throughout
+    (com_y <= 1.5e-3 vs 1.6e-3 units, histogram L1 <= 0.13 vs 0.15 from frame 100 on)."""
     from oracle.ora import Oracle
-    eng, ora = abi.Engine(0), Oracle(omp=True)
-    se, so = scenes.config1(eng), scenes.config1(ora)
+    eng, ora, twin = abi.Engine(0), Oracle(omp=True), Oracle(omp=True)
+    se, so, st = scenes.config1(eng), scenes.config1(ora), scenes.config1(twin)
     se.sph.use_step_frame = True
-    se.start(); so.start()
+    se.start(); so.start(); st.start()
+    P0 = twin.download_particles()
+    P0[:, 0:3] = np.nextafter(P0[:, 0:3], np.float32(np.inf))
+    twin.upload_particles(P0)
     checkpoints = {}
+    env = dict(comy=0.0, hist=0.0, ke=0.0)                 # running maxima of the oracle-vs-twin distances
+    floor = dict(comy=2e-4, hist=5e-3, ke=1e-2)
+    factor = dict(comy=3.0, hist=3.0, ke=8.0)
+    trajectory = []
     for f in range(1, 1001):
-        se.frame(); so.frame()
+        se.frame(); so.frame(); st.frame()
         if f in (10, 100, 300, 1000):
             checkpoints[f] = (aggregates(eng.download_particles()), aggregates(ora.download_particles()))
+        if f % 50 == 0:
+            P, Q, T = eng.download_particles(), ora.download_particles(), twin.download_particles()
+            a, b, c = aggregates(P), aggregates(Q), aggregates(T)
+            dist = lambda x, X, y, Y: dict(comy=abs(x["com"][1] - y["com"][1]), hist=float(np.abs(rho_histogram(X) - rho_histogram(Y)).sum()),
+                                           ke=abs(x["ke"] - y["ke"]) / max(y["ke"], 1e-9))          # noqa: E731
+            chaos, got = dist(c, T, b, Q), dist(a, P, b, Q)
+            for k in env:
+                env[k] = max(env[k], chaos[k])
+                assert got[k] <= factor[k] * env[k] + floor[k], \
+                    f"frame {f}: engine-oracle {k} distance {got[k]:.4g} > {factor[k]} x the oracle's own one-ulp spread {env[k]:.4g} + {floor[k]}"
+            trajectory.append((f, round(a["com"][1], 4), round(b["com"][1], 4), round(got["hist"], 4), round(chaos["hist"], 4)))
     box = 10.0
     for f, (a, b) in checkpoints.items():
         assert np.all(np.isfinite(list(a["com"]) + [a["ke"], a["vmax"]])), f"frame {f}: engine state not finite"
@@ -42,16 +77,13 @@ def test_config1_1000_frames_bounded_drift():
         assert np.abs(a["com"] - b["com"]).max() <= (1e-4 if tight else 0.02) * box, (f, a["com"], b["com"])
         assert abs(a["pe"] - b["pe"]) <= (1e-4 if tight else 0.03) * abs(b["pe"]), (f, a["pe"], b["pe"])
         assert abs(a["rho_mean"] - b["rho_mean"]) <= (1e-4 if tight else 0.03) * b["rho_mean"], (f, a["rho_mean"], b["rho_mean"])
-        # kinetic energy: 35 % relative + a noise floor of 0.25 m/s rms (the residual jitter of a
-        # settled tank is chaotic: 0.23 vs 0.34 m/s rms at frame 1000 is the same physical state)
-        ke_floor = 0.0 if tight else 0.5 * 16384 * 0.2 * 0.25 ** 2
-        assert abs(a["ke"] - b["ke"]) <= (1e-3 if tight else 0.35) * b["ke"] + ke_floor, (f, a["ke"], b["ke"])
+        if tight:
+            assert abs(a["ke"] - b["ke"]) <= 1e-3 * b["ke"], (f, a["ke"], b["ke"])
         assert abs(a["ymax"] - b["ymax"]) <= (1e-3 if tight else 0.15) * box, (f, a["ymax"], b["ymax"])
     # the fluid has settled into the lower part of the box on both sides
     a, b = checkpoints[1000]
     assert a["com"][1] < 3.0 and b["com"][1] < 3.0
-    print({f: {k: (np.round(x[k], 4), np.round(y[k], 4)) for k in ("ke", "pe", "vmax", "rho_mean", "ymax")}
-           for f, (x, y) in checkpoints.items()})
+    print("frame, com_y engine, com_y oracle, histogram L1 engine-oracle, oracle-twin:", trajectory)
 
 
 def test_scene4_two_phase_obb_obstacle_600_frames_bounded_drift_per_phase():
