@@ -299,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void k_rank_move(const uint32_t* __restrict
         v.x += hdt * acc.x; v.y += hdt * acc.y; v.z += hdt * acc.z;
         p.x += v.x * dt; p.y += v.y * dt; p.z += v.z * dt;
         // positions alone, 12 bytes per slot: what the density kernel's candidate loads read (physics_kernels.h)
-        if (pos3) { pos3[3 * d] = p.x; pos3[3 * d + 1] = p.y; pos3[3 * d + 2] = p.z; }
+        if (pos3) *(Float3U*)(pos3 + 3 * (size_t)d) = Float3U{p.x, p.y, p.z};        // one 12-byte store
     } else {
         dst.acc[d] = src.acc[s];
         dst.rhoP[d] = src.rhoP[s];

@@ -932,8 +932,11 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
         };
         auto fetch = [&](Stage& S) {
             // the row the slowest lane is in (a lane between words counts with the word it starts next)
-            while (curRow < 9 && !__any((w != 0 ? rowOfW : (nxt >> 3)) <= curRow)) curRow++;
-            const int limit = min(curRow + rowSlack, 8);
+            int limit = 8;
+            if (rowSlack < 8) {                                  // wave-uniform; 8 = ungated: no bookkeeping at all
+                while (curRow < 9 && !__any((w != 0 ? rowOfW : (nxt >> 3)) <= curRow)) curRow++;
+                limit = min(curRow + rowSlack, 8);
+            }
             int j0, j1;
             S.h0 = pop(j0, limit);
             S.h1 = pop(j1, limit);
@@ -987,7 +990,7 @@ __global__ __launch_bounds__(kBlock) void k_half_step(int n, float dt, float4* _
     p.x += v.x * dt; p.y += v.y * dt; p.z += v.z * dt;
     velV[s] = v;
     posM[s] = p;
-    if (pos3) { pos3[3 * s] = p.x; pos3[3 * s + 1] = p.y; pos3[3 * s + 2] = p.z; }   // see k_density_pressure_rows
+    if (pos3) *(Float3U*)(pos3 + 3 * (size_t)s) = Float3U{p.x, p.y, p.z};             // see k_density_pressure_rows
 }
 
 // CS_VvFullStep (compute:325-334)

@@ -71,6 +71,8 @@ __host__ __device__ __forceinline__ int row_index(int ryT, int y, int z) {
 }
 __host__ __device__ __forceinline__ int tiles_along(int r, int log) { return (r + (1 << log) - 1) >> log; }
 
+struct __attribute__((packed, aligned(4))) Float3U { float x, y, z; };   // 12-byte access at a 4-byte aligned address
+
 // SoA particle state, one "set".  Everything is indexed by SLOT (position in the
 // (cell, id)-sorted order of the last grid build; slot == id right after an upload).
 struct StateSet {
