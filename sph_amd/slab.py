@@ -296,6 +296,7 @@ class NeighbourComm:
         """True on every rank if `flag` is set on any (one tiny all-reduce; not on the data path)."""
         t = self.torch.tensor([1 if flag else 0], dtype=self.torch.int64, device=self._dev())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        self.host_waits += 1                          # the flag is read on the host
         return bool(int(t.item()))
 
     def allreduce_sum(self, value: int) -> int:

@@ -173,3 +173,78 @@ def test_uniform_mass_density_is_bitwise_the_oracles():
         x, y = eng.download_particles(), ora.download_particles()
         assert np.array_equal(x[:, 9].view(np.uint32), y[:, 9].view(np.uint32)), f"frame {f}: density"
     eng.destroy(); ora.destroy()
+
+
+def engine_with_env(**env):
+    """An engine created under the given SPH_HIP_* switches (all of them are read once, in sph_create)."""
+    for k, v in env.items():
+        os.environ[k] = v
+    try:
+        return abi.Engine(0)
+    finally:
+        for k in env:
+            del os.environ[k]
+
+
+@pytest.mark.parametrize("which,sub", [(4, 1), (4, 2), (2, 1)])
+def test_tail_inside_the_force_kernel_equals_the_separate_pass_bitwise(which, sub):
+    """sph_step_frame on one GPU applies CS_VvFullStep + CS_BoundObs (+ CS_VelocityDamping) inside the force kernel
+    (k_force_xsph_hits<MODE, TAIL=true>, new positions into the other position array).  Same bits as the separate
+    tail pass (SPH_HIP_FUSE_TAIL=0) and as kernel-by-kernel dispatch, collision counter included, with obstacles
+    and a moving boundary in the scene."""
+    a, b, c = abi.Engine(0), engine_with_env(SPH_HIP_FUSE_TAIL="0"), abi.Engine(0)
+    ss = [scenes.unity_scene(e, which=which, scale_count=0.05) for e in (a, b, c)]
+    for s, sf in zip(ss, (True, True, False)):
+        s.sph.use_step_frame = sf
+        s.sph.subSteps = sub
+        s.start()
+    for f in range(6):
+        for s in ss:
+            s.frame()
+        pa, pb, pc = a.download_particles(), b.download_particles(), c.download_particles()
+        assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32)), f"frame {f}: fused vs separate tail"
+        assert np.array_equal(pa.view(np.uint32), pc.view(np.uint32)), f"frame {f}: fused vs dispatch"
+        assert a.read_counter(abi.CTR_COLLISIONS) == b.read_counter(abi.CTR_COLLISIONS) == c.read_counter(abi.CTR_COLLISIONS)
+    a.destroy(); b.destroy(); c.destroy()
+
+
+@pytest.mark.parametrize("n", [20000, 4096 + 77])
+def test_lds_staged_density_equals_the_rows_kernel_bitwise(n, capfd):
+    """SPH_HIP_LDS_DENSITY=1 (k_density_pressure_lds: workgroup windows of pos3 staged in LDS) is an opt-in experiment
+    (profiles/r3_lds_density); it has to leave the same density, pressure, hit mask and neighbour records as the
+    default kernel: same bits frame after frame, and the decoded hit lists equal the oracle's neighbour lists."""
+    from oracle.ora import Oracle
+    from tests.util import assert_hit_lists_equal
+    a, b, ora = abi.Engine(0), engine_with_env(SPH_HIP_LDS_DENSITY="1", SPH_HIP_LDS_STATS="1"), Oracle()
+    sa, sb, so = scenes.config1(a, n=n), scenes.config1(b, n=n), scenes.config1(ora, n=n)
+    for s in (sa, sb):
+        s.sph.use_step_frame = True
+    for s in (sa, sb, so):
+        s.start()
+    for f in range(5):
+        state = ora.download_particles()
+        a.upload_particles(state); b.upload_particles(state)
+        sa.frame(); sb.frame(); so.frame()
+        pa, pb = a.download_particles(), b.download_particles()
+        assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32)), f"frame {f}"
+        assert np.array_equal(pb[:, 9].view(np.uint32), ora.download_particles()[:, 9].view(np.uint32)), f"frame {f}: density"
+    # the mask itself: grid, half step (it leaves the 12-byte positions both kernels read) and density dispatched on
+    # all three from the same state, then decoded
+    for e, s in ((a, sa), (b, sb), (ora, so)):
+        e.upload_particles(state)
+        cells = s.sph.gridResolutionX * s.sph.gridResolutionY * s.sph.gridResolutionZ
+        e.dispatch(abi.K_CLEAR_GRID, cells); e.dispatch(abi.K_BUILD_GRID, e.n)
+        e.dispatch(abi.K_VV_HALF_STEP, e.n); e.dispatch(abi.K_DENSITY_PRESSURE, e.n)
+    sa_, ca, la = a.download_hit_lists(256)
+    sb_, cb, lb = b.download_hit_lists(256)
+    assert sa_ == sb_ == 1
+    assert np.array_equal(ca, cb) and np.array_equal(la, lb)
+    assert_hit_lists_equal(b, ora, 256, "lds kernel: ")
+    capfd.readouterr()
+    a.destroy(); b.destroy(); ora.destroy()
+    import re
+    m = re.search(r"k_density_pressure_lds: lane-steps from LDS (\d+), from memory (\d+)", capfd.readouterr().err)
+    assert m, "the LDS kernel's statistics line is missing: was it launched at all?"
+    from_lds, from_memory = int(m.group(1)), int(m.group(2))
+    # both routes of the kernel ran: most lane-steps from the staged windows, the uncovered rest from memory
+    assert from_lds > 6 * 9 * n * 0.3 and from_memory < 0.5 * from_lds, (from_lds, from_memory)
