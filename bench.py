@@ -172,7 +172,7 @@ def main(argv=None):
 
     from sph_amd import abi, scenes
     from sph_amd.benchutil import (DENSITY_BYTES_PER_PARTICLE, FORCE_BYTES_PER_PARTICLE, HBM_PEAK_GBPS, MEASURED_LIMITER,
-                                   counter_run, measured_traffic, ta_busy_frac, valu_issue)
+                                   counter_run, l1_access_rate, measured_traffic, ta_busy_frac, valu_issue)
 
     if args.gpus > 1:
         from sph_amd import slab
@@ -258,12 +258,14 @@ def main(argv=None):
                      "alg_bytes_per_particle": FORCE_BYTES_PER_PARTICLE, "avg_launch_ms": tm["force_ms"],
                      "valu_issue": valu_issue(run, "k_force_xsph_hits", tm["force_ms"]),
                      "ta_busy_frac": ta_busy_frac(run, "k_force_xsph_hits", tm["force_ms"]),
+                     "l1_accesses_per_clk_per_cu": l1_access_rate(run, "k_force_xsph_hits"),
                      "density_kernel": {"achieved": dens_gbps, "frac": frac(dens_gbps),
                                         "alg_bytes_per_particle": DENSITY_BYTES_PER_PARTICLE,
                                         "avg_launch_ms": tm["density_ms"],
                                         "traffic": measured_traffic(run, "k_density_pressure_rows"),
                                         "valu_issue": valu_issue(run, "k_density_pressure_rows", tm["density_ms"]),
-                                        "ta_busy_frac": ta_busy_frac(run, "k_density_pressure_rows", tm["density_ms"])}},
+                                        "ta_busy_frac": ta_busy_frac(run, "k_density_pressure_rows", tm["density_ms"]),
+                                        "l1_accesses_per_clk_per_cu": l1_access_rate(run, "k_density_pressure_rows")}},
         "stage_ms": {k: (None if v is None else round(v, 4)) for k, v in tm.items() if k.endswith("_ms")},
     }
     if not args.no_cpu_baseline:

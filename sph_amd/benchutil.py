@@ -10,7 +10,8 @@ DENSITY_BYTES_PER_PARTICLE = 28
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
 # what the counters say limits the two neighbour kernels; `bound` stays the contract's
 # roofline (the one `peak` and `frac` are priced against)
-MEASURED_LIMITER = "texture-addresser gather issue + VALU issue (candidate tests), not HBM: see valu_issue, ta_busy_frac"
+MEASURED_LIMITER = ("vector-memory path (texture addresser + vector-L1 accesses of the candidate gathers) + VALU issue, not HBM: "
+                    "see valu_issue, ta_busy_frac, l1_accesses_per_clk_per_cu")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -63,5 +64,16 @@ def ta_busy_frac(run, kernel, launch_ms=None, cus=256):
         if "GRBM_GUI_ACTIVE" in k:
             return busy / (k["GRBM_GUI_ACTIVE"] / 8.0)
         return busy / (2.4e9 * launch_ms * 1e-3)
+    except Exception:
+        return None
+
+
+def l1_access_rate(run, kernel, cus=256):
+    """Vector-L1 (TCP) accesses per clock and CU over the kernel's own cycles, from ONE counter run
+    (TCP_TOTAL_CACHE_ACCESSES_sum / CUs over GRBM_GUI_ACTIVE / 8).  The path sustains 1.0-1.3 per clock on synthetic
+    gathers with the addresser 98 % busy (profiles/r3_wave_trace/tcp_access_rate_microbench.txt)."""
+    try:
+        k = run["kernels"][kernel]
+        return k["TCP_TOTAL_CACHE_ACCESSES_sum"] / cus / (k["GRBM_GUI_ACTIVE"] / 8.0)
     except Exception:
         return None

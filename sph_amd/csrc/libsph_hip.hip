@@ -60,6 +60,8 @@ struct sph_ctx {
     // step leave the waves waiting 56 % of their cycles (profiles/r3_lds_density/)
     bool ldsDensity = false;
     unsigned long long* ldsStats = nullptr;   // SPH_HIP_LDS_STATS=1: [0] lane-steps from LDS, [1] from memory, [2] chunks staged
+    unsigned launchLds = 0;   // dynamic LDS of the next LAUNCH_T (occupancy experiments: densLdsPad / forceLdsPad)
+    unsigned densLdsPad = 0, forceLdsPad = 0;   // SPH_HIP_DENSITY_LDS_KB / SPH_HIP_FORCE_LDS_KB
     bool fuseTailOk = true;   // SPH_HIP_FUSE_TAIL=0: sph_step_frame keeps the separate tail pass (A/B)
     bool tailFusedLast = false;   // the last CS_ForceXSPH launch applied the frame's tail itself
     float4* color = nullptr;       // by id
@@ -225,11 +227,11 @@ int fail(sph_ctx* c, int code, const char* fmt, ...) {
         hipEvent_t s_ = ((c)->tev && (e0) >= 0) ? (c)->tev[(e0) < 0 ? 0 : (e0)] : (hipEvent_t) nullptr;                \
         hipEvent_t t_ = ((c)->tev && (e1) >= 0) ? (c)->tev[(e1) < 0 ? 0 : (e1)] : (hipEvent_t) nullptr;                \
         if (s_ || t_) {                                                                                               \
-            hipExtLaunchKernelGGL(kernel, grid, dim3(kBlock), 0, (c)->stream, s_, t_, 0, __VA_ARGS__);                \
+            hipExtLaunchKernelGGL(kernel, grid, dim3(kBlock), (c)->launchLds, (c)->stream, s_, t_, 0, __VA_ARGS__);                \
             if (s_) *(c)->tevMask |= 1u << ((e0) < 0 ? 0 : (e0));                                                     \
             if (t_) *(c)->tevMask |= 1u << ((e1) < 0 ? 0 : (e1));                                                     \
         } else {                                                                                                      \
-            hipLaunchKernelGGL(kernel, grid, dim3(kBlock), 0, (c)->stream, __VA_ARGS__);                              \
+            hipLaunchKernelGGL(kernel, grid, dim3(kBlock), (c)->launchLds, (c)->stream, __VA_ARGS__);                  \
         }                                                                                                             \
     } while (0)
 
@@ -566,6 +568,7 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
             uint32_t* const mask = c->useHitMask ? c->hitMask : (uint32_t*)nullptr;
             const uint32_t* const skeys = c->slab ? (const uint32_t*)c->sortedKeys : (const uint32_t*)nullptr;
             const int d0 = c->tevSub ? E_DENS0 : -1, d1 = c->tevSub ? E_DENS1 : -1;
+            c->launchLds = c->densLdsPad;
             if (uniform && !c->slab && c->ldsDensity && mask) {
                 // candidates staged in LDS per workgroup (k_density_pressure_lds): opt-in experiment, SPH_HIP_LDS_DENSITY=1
                 if (c->ldsStats)
@@ -584,6 +587,7 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
                 LAUNCH_T(c, d0, d1, k_density_pressure_rows<false>, dim3(nb), c->dp, (const float4*)s.posM, (const float*)s.rho0, s.rhoP,
                          (const int*)c->cellCum, (const int*)c->counters, mask, c->capacity, nbr, skeys, c->blockInts,
                          (const float*)nullptr, 0.0f);
+            c->launchLds = 0;
             if (c->slab)
                 hipLaunchKernelGGL(k_slab_shift_reduce, dim3((nb + kShiftPerGroup - 1) / kShiftPerGroup), dim3(kBlock), 0, c->stream, c->blockInts, nb,
                                    c->counters + SPH_CTR_MAX_PLANE_SHIFT);
@@ -637,6 +641,7 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
              (const float2*)s.rhoP, s.acc, velOut, (const int*)c->cellCum, (const int*)c->counters, (const uint32_t*)c->hitMask, \
              c->capacity, (const float4*)c->nbrA, (const float4*)c->nbrB, ph, fused ? 1 : 0, c->rowSlack, tail)
 #define FORCE_HITS(MODE_) do { if (fuseTail) FORCE_HITS_T(MODE_, true); else FORCE_HITS_T(MODE_, false); } while (0)
+            c->launchLds = c->forceLdsPad;
             if (mode == 2) FORCE_HITS(2);
             else if (mode == 1) FORCE_HITS(1);
             else if (mode == 0) FORCE_HITS(0);
@@ -645,6 +650,7 @@ int dispatchKernel(sph_ctx* c, int id, bool fused = false, bool lastSub = false,
                          (const float2*)s.rhoP, s.acc, velOut, (const int*)c->cellCum, (const int*)c->counters, fused ? 1 : 0);
 #undef FORCE_HITS
 #undef FORCE_HITS_T
+            c->launchLds = 0;
             if (wgPhase != 1) c->velCur = 1 - c->velCur;
             if (fuseTail) {   // what the separate tail pass leaves behind
                 c->posCur = 1 - c->posCur;
@@ -718,6 +724,17 @@ int exportLists(sph_ctx* c, int32_t* counts, int32_t* lists, int max_neighbors, 
 
 extern "C" {
 
+#ifdef SPH_WG_TRACE
+// debug builds only: the per-wave trace of the last density (0) / force (1) launch; out = waves x 3 u64
+int sph_debug_wave_trace(int kernel, unsigned long long* out, int waves) {
+    if (kernel < 0 || kernel > 1 || waves < 0 || waves > kTraceWaves) return SPH_E_INVALID;
+    if (hipDeviceSynchronize() != hipSuccess) return SPH_E_HIP;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_waveTrace), (size_t)waves * 3 * sizeof(unsigned long long),
+                               (size_t)kernel * kTraceWaves * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess
+               ? SPH_OK : SPH_E_HIP;
+}
+#endif
+
 const char* sph_version(void) { return "libsph_hip 0.1 (gfx950, hand-written HIP)"; }
 
 const char* sph_last_error(const sph_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
@@ -741,6 +758,8 @@ int sph_create(sph_ctx** out, int device_id) {
     if (const char* um = getenv("SPH_HIP_UNIFORM_MASS")) c->uniformMassOk = atoi(um) != 0;
     if (const char* up = getenv("SPH_HIP_UNIFORM_PHASE")) c->uniformPhaseOk = atoi(up) != 0;
     if (const char* ft = getenv("SPH_HIP_FUSE_TAIL")) c->fuseTailOk = atoi(ft) != 0;
+    if (const char* v = getenv("SPH_HIP_DENSITY_LDS_KB")) c->densLdsPad = (unsigned)atoi(v) * 1024u;
+    if (const char* v = getenv("SPH_HIP_FORCE_LDS_KB")) c->forceLdsPad = (unsigned)atoi(v) * 1024u;
     if (const char* ld = getenv("SPH_HIP_LDS_DENSITY")) c->ldsDensity = atoi(ld) != 0;
     if (const char* gf = getenv("SPH_HIP_GHOST_FORCE")) c->skipGhostForce = atoi(gf) == 0;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {

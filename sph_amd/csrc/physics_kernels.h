@@ -45,8 +45,8 @@ constexpr int kMaskStage = 16;   // of which the density kernel stages this many
 // XCD sweeps several whole cell rows and re-uses in its own L2 the rows it fetched for the row
 // before, short enough that every XCD gets many runs.  Bijective for any grid size; affects speed
 // only, never results.
-__device__ __forceinline__ int xcd_tile(int bid, int nwg, int run) {
-    const int span = 8 * run;
+__device__ __forceinline__ int xcd_tile(const DevParams& P, int bid, int nwg) {
+    const int run = P.xcdRun, span = 8 * run;
     const int full = nwg / span * span;
     if (bid >= full) return bid;                     // ragged tail: identity
     const int g = bid / span, w = bid - g * span;
@@ -136,7 +136,8 @@ __device__ __forceinline__ void density_rows_body(const DevParams& P, const floa
                                                   uint32_t (*maskStage)[kBlock]) {
     const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
     const int nRanges = capped ? 27 : 9;
-    const int s = xcd_tile(blockIdx.x, gridDim.x, P.xcdRun) * kBlock + threadIdx.x;
+    const int tile = xcd_tile(P, blockIdx.x, gridDim.x);
+    const int s = tile * kBlock + threadIdx.x;
     const bool valid = s < P.n;
     const float4 p = posM[valid ? s : 0];
     if (slabKeys) {
@@ -301,6 +302,7 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_rows(DevParams P, c
                                                                   int* __restrict__ slabShift,
                                                                   const float* __restrict__ pos3, float uniformMass) {
     __shared__ uint32_t maskStage[kMaskStage][kBlock];
+    SPH_WAVE_TRACE(0);
     density_rows_body<UNIFORM_MASS>(P, posM, rho0, rhoP, cellCum, counters, hitMask, maskStride, nbr, slabKeys, slabShift, pos3,
                                     uniformMass, maskStage);
 }
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(kBlock) void k_density_pressure_lds(DevParams P, co
         return;
     }
     const int tid = threadIdx.x;
-    const int s = xcd_tile(blockIdx.x, gridDim.x, P.xcdRun) * kBlock + tid;
+    const int s = xcd_tile(P, blockIdx.x, gridDim.x) * kBlock + tid;
     const bool valid = s < P.n;
     const float4 p = posM[valid ? s : 0];
     const uint32_t ph = (!nbr.a || !valid) ? 0u : nbr.phaseOfSlot ? nbr.phaseOfSlot[s] : nbr.phaseOfId[nbr.origId[s]];
@@ -784,7 +786,7 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_rows(DevParams P, const f
                                                             const int* __restrict__ counters, int zeroDeadAcc) {
     __shared__ int queue[kHitQueue][kBlock];
     const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
-    const int wg = xcd_tile(blockIdx.x, gridDim.x, P.xcdRun);
+    const int wg = xcd_tile(P, blockIdx.x, gridDim.x);
     if (P.wgBand && P.wgBand[wg] != P.wgPhase) return;         // slab mode: the other launch of the pair does this one
     const int s = wg * kBlock + threadIdx.x;
     const ForceSelf me = force_load_self(P, s, posM, velIn, rhoP);
@@ -821,8 +823,9 @@ __global__ __launch_bounds__(kBlock) void k_force_xsph_hits(DevParams P, const f
     __shared__ uint8_t codeOf[kMaskWords][kBlock];       // (row << 3) | word-in-row of every kept word
     int (*const wordOf)[kBlock] = lds;                   // [kMaskWords]
     int (*const rowA)[kBlock] = lds + kMaskWords;        // [9] first slot of every row
+    SPH_WAVE_TRACE(1);
     const bool capped = counters[SPH_CTR_BIN_OVERFLOW] != 0;   // wave-uniform
-    const int wg = xcd_tile(blockIdx.x, gridDim.x, P.xcdRun);
+    const int wg = xcd_tile(P, blockIdx.x, gridDim.x);
     if (P.wgBand && P.wgBand[wg] != P.wgPhase) return;         // slab mode: the other launch of the pair does this one
     const int s = wg * kBlock + threadIdx.x;
     const ForceSelf me = force_load_self(P, s, posM, velIn, rhoP);

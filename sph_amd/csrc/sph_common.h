@@ -85,4 +85,31 @@ struct StateSet {
     uint8_t*  phase;   // slab mode: phase (spawn box) of the particle in this slot; elsewhere phases are kept by id
 };
 
+// Debug builds only (-DSPH_WG_TRACE, scripts/gpu_wave_trace.sh): every wave of the two neighbour kernels leaves its
+// begin / end time (100 MHz wall clock) and where it ran, to see how much of a launch is tail.
+#ifdef SPH_WG_TRACE
+constexpr int kTraceWaves = 1 << 17;
+__device__ unsigned long long g_waveTrace[2][kTraceWaves][3];
+struct WaveTrace {
+    int k;
+    unsigned long long t0;
+    __device__ __forceinline__ explicit WaveTrace(int kernel) : k(kernel), t0(wall_clock64()) {}
+    __device__ __forceinline__ ~WaveTrace() {
+        if ((threadIdx.x & 63) == 0) {
+            const size_t w = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+            if (w < (size_t)kTraceWaves) {
+                const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
+                const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+                g_waveTrace[k][w][0] = t0;
+                g_waveTrace[k][w][1] = wall_clock64();
+                g_waveTrace[k][w][2] = ((unsigned long long)xcc << 32) | hw;
+            }
+        }
+    }
+};
+#define SPH_WAVE_TRACE(k) WaveTrace waveTrace_(k)
+#else
+#define SPH_WAVE_TRACE(k)
+#endif
+
 }  // namespace sph
