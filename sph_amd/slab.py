@@ -149,7 +149,7 @@ class DevicePort:
 # ------------------------------------------------------------------------------------------------
 # communication: neighbour-to-neighbour send/recv of record tensors
 # ------------------------------------------------------------------------------------------------
-HDR_COUNT, HDR_NEED = 0, 1          # int64 fields of a message's header row (64 bytes = 8 fields)
+HDR_COUNT, HDR_NEED, HDR_FATAL = 0, 1, 2   # int64 fields of a message's header row (64 bytes = 8 fields)
 FIRST_BOUND = 4096                   # records both ends of a face expect in the first message (before any was seen)
 
 
@@ -184,6 +184,8 @@ class NeighbourComm:
         self.rbuf = [None, None]
         self.exchanges = self.rounds = self.host_waits = 0
         self.padded_records = self.sent_records = 0
+        self.peer_fatal = (False, False)  # the left / right neighbour announced in its last header that it is stopping
+        self.error = None                 # a failure this exchange detected itself (the caller makes the stop collective)
 
     def _dev(self):
         return self.torch.device("cpu") if self.stage_cpu else self.device
@@ -211,14 +213,18 @@ class NeighbourComm:
             self.rbuf[side] = cur = new
         return cur
 
-    def _message(self, side, recs, base, bound, need):
+    def empty(self):
+        """A message of no records."""
+        return self.torch.empty((0, REC), dtype=self.torch.uint8, device=self._dev())
+
+    def _message(self, side, recs, base, bound, need, fatal=False):
         """The tensor to send: header row + the first min(n, bound) records + padding up to `bound` rows.  `base`: a
         buffer whose rows 1.. already hold the records (DevicePort.send_bases), used in place."""
         torch = self.torch
         n = int(recs.shape[0])
         dev = self._dev()
         hdr = torch.zeros(REC // 8, dtype=torch.int64)
-        hdr[HDR_COUNT], hdr[HDR_NEED] = n, int(need)
+        hdr[HDR_COUNT], hdr[HDR_NEED], hdr[HDR_FATAL] = n, int(need), 1 if fatal else 0
         in_place = (base is not None and base.device == dev and base.shape[0] >= bound + 1 and
                     (n == 0 or recs.data_ptr() == base[1:].data_ptr()))
         if in_place:
@@ -231,10 +237,12 @@ class NeighbourComm:
         msg[0:1].view(torch.int64).copy_(hdr.view(1, -1))
         return msg
 
-    def exchange(self, to_left, to_right, need=0, bases=None):
+    def exchange(self, to_left, to_right, need=0, bases=None, fatal=False):
         """Send to_left to rank-1 and to_right to rank+1; returns (from_left, from_right).  `need` (an int) rides in
         the header to both neighbours; theirs end up in self.peer_need.  `bases`: the two buffers the records sit in
-        behind a spare header row (DevicePort.send_bases), or None."""
+        behind a spare header row (DevicePort.send_bases), or None.  `fatal`: this rank is about to stop with an error
+        and says so in the header (the neighbours' announcements end up in self.peer_fatal).  A message beyond the
+        capacity is still transferred completely -- both ends stay in step -- and reported in self.error."""
         torch = self.torch
         peers = [self.rank - 1 if self.rank > 0 else None, self.rank + 1 if self.rank < self.world - 1 else None]
         if peers[0] is None and peers[1] is None:
@@ -247,7 +255,7 @@ class NeighbourComm:
             if peers[k] is None:
                 continue
             bound = self.bound_send[k]
-            msg = self._message(k, out[k], None if bases is None else bases[k], bound, need)
+            msg = self._message(k, out[k], None if bases is None else bases[k], bound, need, fatal)
             sent_first[k] = min(int(out[k].shape[0]), bound)
             self.sent_records += sent_first[k]
             self.padded_records += bound - sent_first[k]
@@ -260,8 +268,13 @@ class NeighbourComm:
         self.host_waits += 1
         n_from = [int(hdrs[k, HDR_COUNT]) if peers[k] is not None else 0 for k in (0, 1)]
         self.peer_need = tuple(int(hdrs[k, HDR_NEED]) if peers[k] is not None else 0 for k in (0, 1))
-        if self.cap and max(n_from) > self.cap:
-            raise RuntimeError(f"incoming face message of {max(n_from)} records exceeds the message capacity {self.cap}")
+        self.peer_fatal = tuple(peers[k] is not None and int(hdrs[k, HDR_FATAL]) != 0 for k in (0, 1))
+        # beyond the capacity: the sender and the receiver both see it (the count is in the header), both finish the
+        # transfer as announced and report it; the caller stops the run on every rank (SlabEngine._stop_together)
+        n_out_max = max(int(out[k].shape[0]) for k in (0, 1) if peers[k] is not None)
+        if self.cap and max(max(n_from), n_out_max) > self.cap:
+            self.error = (f"face message of {max(max(n_from), n_out_max)} records exceeds the message capacity {self.cap} "
+                          f"(rank {self.rank})")
         # a message that outgrew its bound: exactly the missing records, in a second transfer
         sends, recvs = [], []
         for k in (0, 1):
@@ -292,12 +305,16 @@ class NeighbourComm:
             res.append(got)
         return res[0], res[1]
 
-    def any_rank(self, flag: bool) -> bool:
-        """True on every rank if `flag` is set on any (one tiny all-reduce; not on the data path)."""
-        t = self.torch.tensor([1 if flag else 0], dtype=self.torch.int64, device=self._dev())
+    def max_code(self, code: int) -> int:
+        """The largest `code` of any rank, on every rank (one tiny all-reduce; not on the data path)."""
+        t = self.torch.tensor([int(code)], dtype=self.torch.int64, device=self._dev())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        self.host_waits += 1                          # the flag is read on the host
-        return bool(int(t.item()))
+        self.host_waits += 1                          # the code is read on the host
+        return int(t.item())
+
+    def any_rank(self, flag: bool) -> bool:
+        """True on every rank if `flag` is set on any."""
+        return self.max_code(1 if flag else 0) != 0
 
     def allreduce_sum(self, value: int) -> int:
         t = self.torch.tensor([value], dtype=self.torch.int64, device=self._dev())
@@ -390,6 +407,7 @@ class SlabEngine:
         # shift that large; if so the frame's owned particles are routed to their owners all-to-all (SURVEY 8e's
         # fallback, _reroute) instead of being lost.
         self.far_guard = True
+        self._fatal = None               # why this rank has to stop (the stop itself is collective: _agree / _stop_together)
         self.reroutes = 0
         self.band_misses = 0
         self.band_fraction = 0.0       # share of the last force kernel that ran before the pack
@@ -516,6 +534,39 @@ class SlabEngine:
         widths = [self.cuts[r + 1] - self.cuts[r] for r in (self.rank - 1, self.rank + 1) if 0 <= r < self.world]
         return bool(widths) and shift >= min(widths)
 
+    # ---- stopping together
+    # A failure on one rank (a face message or a slab beyond its capacity, a HIP error) must end the run on EVERY rank:
+    # a rank that simply raised would leave its neighbours waiting in their next send/recv until the process group's
+    # timeout.  The failing rank keeps `_fatal` and stays in step: with more than two ranks the per-frame code
+    # all-reduce (the one that also carries the far-jump flag) tells everybody, with two the header of the face
+    # message does; all ranks raise at the same point of the same frame.
+    def _agree(self, far: bool) -> bool:
+        """More than two ranks: one all-reduce per frame.  Returns whether some rank saw a far jump; raises on every
+        rank if some rank has failed."""
+        if self.world < 3:
+            return False
+        code = self.comm.max_code(2 if self._fatal else (1 if (far and self.far_guard) else 0))
+        if code >= 2:
+            raise RuntimeError(self._fatal or "another rank of the slab run stopped with an error (see its message)")
+        return code == 1
+
+    def _stop_together(self):
+        """After a face exchange: raise on both ranks of a face if either announced or detected a failure."""
+        if self.comm.error and not self._fatal:
+            self._fatal = self.comm.error
+        # (more than two ranks: a rank that left here would be missed in the next frame's all-reduce, which is where
+        # everybody stops -- _agree)
+        if self.world < 3 and (self._fatal or any(self.comm.peer_fatal)):
+            raise RuntimeError(self._fatal or "the neighbouring rank of the slab run stopped with an error (see its message)")
+
+    def _guarded(self, fn, *args):
+        """fn(*args), or two empty messages and `_fatal` set if it failed (the stop is made collective later)."""
+        try:
+            return fn(*args)
+        except (abi.SphError, RuntimeError, MemoryError) as exc:
+            self._fatal = self._fatal or f"rank {self.rank}: {exc}"
+            return self.comm.empty(), self.comm.empty()
+
     def _reroute(self):
         """SURVEY 8e's fallback for particles that jumped further than the neighbouring slab: every rank takes its owned
         particles off the device and sends each to the rank that owns its CURRENT plane (all-to-all by searchsorted on
@@ -556,7 +607,8 @@ class SlabEngine:
         """New cuts by particle count, at most max_cut_shift planes from `base_cuts`, or None if the shares are balanced
         enough.  Collective (every rank calls it in the same frame); needs the grid of the last frame."""
         rx = self.grid[0]
-        hist = self.port.owned_plane_histogram(rx, self.keep[0], self.keep[1] - self.keep[0], self.own[0], self.own[1])
+        hist = (np.zeros(rx, dtype=np.int64) if self._fatal else     # a failed rank stays in step until everybody stops
+                self.port.owned_plane_histogram(rx, self.keep[0], self.keep[1] - self.keep[0], self.own[0], self.own[1]))
         hist = self.comm.allreduce_sum_array(hist)
         cum = np.concatenate([[0], np.cumsum(hist)])
         shares = np.diff(cum[np.asarray(base_cuts)])
@@ -614,8 +666,10 @@ class SlabEngine:
         plane = self._planes(recs["pos"][:, 0])
         dest = np.searchsorted(np.asarray(self.cuts[1:-1]), plane, side="right")
         mine = self.comm.all_to_all_records([recs[dest == r] for r in range(self.world)])
-        if mine.shape[0] > self._capacity:
-            raise RuntimeError(f"re-partition: {mine.shape[0]} particles exceed this slab's capacity of {self._capacity}")
+        over = mine.shape[0] > self._capacity
+        if (self.world > 1 and self.comm.max_code(2 if over else 0) >= 2) or over:       # every rank stops, not just this one
+            raise RuntimeError(f"re-partition: {mine.shape[0]} particles exceed this slab's capacity of {self._capacity}" if over
+                               else "re-partition: another rank's share exceeds its slab's capacity (see its message)")
         x0, x1 = self.own
         self.port.configure(rx, self.keep[0], self.keep[1] - self.keep[0], ry, rz, cap, x0, x1, self._capacity)
         self.port.upload_owned(mine)
@@ -680,14 +734,18 @@ class SlabEngine:
         ran_with = list(self.wk)
         self._adapt(in_flight=False)
         left_below, right_from = self._send_range()
-        to_l, to_r = self.port.pack(left_below, right_from)
+        to_l, to_r = self._guarded(self.port.pack, left_below, right_from)
         if self.frames > 0 and self.world > 1:
-            shift = self.e.read_counter(abi.CTR_MAX_PLANE_SHIFT)                       # came back with pack's counts: no extra sync
+            shift = 0 if self._fatal else self.e.read_counter(abi.CTR_MAX_PLANE_SHIFT)    # came back with pack's counts: no extra sync
             self._note_shift(shift, ran_with)
-            if self.far_guard and self.world > 2 and self.comm.any_rank(self._far_danger(shift)):
+            if self._agree(self._far_danger(shift)):
                 self._reroute()                     # owned particles only from here; pack again for the ghosts
-                to_l, to_r = self.port.pack(left_below, right_from)
-        from_l, from_r = self.comm.exchange(to_l, to_r, need=self._needed(), bases=getattr(self.port, "send_bases", None))
+                to_l, to_r = self._guarded(self.port.pack, left_below, right_from)
+        from_l, from_r = self.comm.exchange(to_l, to_r, need=self._needed(), bases=getattr(self.port, "send_bases", None),
+                                            fatal=bool(self._fatal))
+        self._stop_together()
+        if self._fatal:                             # more than two ranks: everybody learns of it in the next frame's all-reduce
+            return
         self.n = self.port.rebuild(self.keep[0], self.keep[1], from_l, from_r)
         self.e.n = self.n
         self.exchange_s += time.perf_counter() - t0
@@ -707,8 +765,12 @@ class SlabEngine:
 
     def step_frame(self, sub_steps, time_step):
         self.sub_steps = int(sub_steps)
+        if self._fatal and self.world > 2:
+            self._agree(False)                      # raises, on every rank
         if not (self.overlap and self.world > 1):
             self.exchange()
+            if self._fatal:
+                return
             self.e.step_frame(sub_steps, time_step)
             self._refresh_count()
             self.frames += 1
@@ -716,19 +778,25 @@ class SlabEngine:
         # overlapped: frame f's messages are packed inside frame f and travel while its second half runs
         if not self._primed:
             self.exchange()                         # the very first frame needs its ghosts the classic way
+            if self._fatal:
+                return
             self._primed = True
         left_below, right_from = self._send_range(self._cuts_next)      # what the NEXT build's owners and ghosts need
-        self.port.arm_pack(left_below, right_from, self.band_margin)
-        self.e.step_frame(sub_steps, time_step)     # returns once everything is enqueued (one sync: survivor count)
-        self._refresh_count()
-        if self.frames > 0:
-            self.band_misses += self.e.read_counter(abi.CTR_BAND_MISSES)    # cached by the build: no sync
+
+        def frame_and_pack():
+            self.port.arm_pack(left_below, right_from, self.band_margin)
+            self.e.step_frame(sub_steps, time_step)     # returns once everything is enqueued (one sync: survivor count)
+            self._refresh_count()
+            if self.frames > 0:
+                self.band_misses += self.e.read_counter(abi.CTR_BAND_MISSES)    # cached by the build: no sync
+            return self.port.pack_wait()            # the band part of the frame is done; the GPU carries on
+
         t0 = time.perf_counter()
-        to_l, to_r = self.port.pack_wait()          # the band part of the frame is done; the GPU carries on
+        to_l, to_r = self._guarded(frame_and_pack)
         self.band_fraction = getattr(self.e, "band_workgroups", 0) / max((self.n + 255) // 256, 1)
-        shift = self.e.read_counter(abi.CTR_MAX_PLANE_SHIFT)
+        shift = 0 if self._fatal else self.e.read_counter(abi.CTR_MAX_PLANE_SHIFT)
         self._note_shift(shift)
-        if self.far_guard and self.world > 2 and self.comm.any_rank(self._far_danger(shift)):
+        if self._agree(self._far_danger(shift)):
             # some particle may belong to a rank the face messages do not reach: let the frame finish, then route every
             # owned particle to its owner; the next frame starts the classic way (ghosts from its own exchange)
             self.e.synchronize()
@@ -742,7 +810,11 @@ class SlabEngine:
         if self.rebalance_every and self.frames > 0 and self.frames % self.rebalance_every == 0:
             # from THIS frame's grid (still valid: the rebuild below invalidates it), relative to the cuts about to apply
             planned = self._plan_recut(self._cuts_next or self.cuts)
-        from_l, from_r = self.comm.exchange(to_l, to_r, need=self._needed(), bases=getattr(self.port, "send_bases", None))
+        from_l, from_r = self.comm.exchange(to_l, to_r, need=self._needed(), bases=getattr(self.port, "send_bases", None),
+                                            fatal=bool(self._fatal))
+        self._stop_together()
+        if self._fatal:
+            return
         if self._cuts_next is not None:          # the records just received were packed for these cuts
             self._apply_cuts(self._cuts_next)
         self._cuts_next = planned

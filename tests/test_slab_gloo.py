@@ -471,3 +471,65 @@ def test_adaptive_ghost_width_with_moving_cuts_equals_single_domain(tmp_path, or
     for r in range(world - 1):
         assert w[r][1] == w[r + 1][0] and w[r][3] == w[r + 1][2], f"face {r}|{r + 1}: {w[r]} vs {w[r + 1]}"
 
+
+
+def _failing_worker(rank, world, port, out_dir, overlap, mode, fail_rank, fail_frame):
+    """A run in which ONE rank fails (mode "pack": its engine refuses the pack of frame `fail_frame`; mode "cap": the face
+    messages outgrow the message capacity).  Every rank writes the frame it stopped in and why."""
+    import datetime
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    from oracle.ora import Oracle
+    from tests.slab_oracle_port import OraclePort
+    oport = OraclePort(Oracle())
+    comm = slab.NeighbourComm(rank, world, torch.device("cpu"), backend="gloo", msg_capacity=12 if mode == "cap" else 0)
+    se = slab.SlabEngine(oport, comm, rank, world, ghost_planes=4 if world == 3 else 8, overlap=overlap)
+    orig = se.set_params
+
+    def set_params(p):
+        oport.set_params_ref(p)
+        orig(p)
+    se.set_params = set_params
+    state = {"frame": 0}
+    if mode == "pack" and rank == fail_rank:
+        for name in ("pack", "pack_wait"):
+            good = getattr(oport, name)
+
+            def failing(*a, _good=good):
+                if state["frame"] >= fail_frame:
+                    raise abi.SphError(-4, "slab message buffer too small (injected)")
+                return _good(*a)
+            setattr(oport, name, failing)
+    sc = small_tank(se)
+    sc.sph.use_step_frame = True
+    stopped = "ran to the end"
+    try:
+        sc.start()
+        for f in range(8):
+            state["frame"] = f
+            sc.frame()
+    except RuntimeError as exc:
+        stopped = f"{state['frame']}|{exc}"
+    with open(os.path.join(out_dir, f"stopped{rank}.txt"), "w") as fh:
+        fh.write(stopped)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,overlap,mode", [(2, False, "pack"), (2, True, "pack"), (3, False, "pack"), (3, True, "pack"),
+                                                (2, True, "cap"), (3, False, "cap")])
+def test_a_failure_on_one_rank_stops_every_rank_in_the_same_frame(tmp_path, oracle_built, world, overlap, mode):
+    """A rank that raised on its own would leave its neighbours waiting in their next send/recv until the process
+    group's timeout.  The failing rank stays in step instead and says so -- in the header of its face
+    messages (two ranks) or in the frame's code all-reduce (more) -- and all ranks raise together."""
+    fail_rank, fail_frame = world - 1, 3
+    mp.spawn(_failing_worker, args=(world, _free_port(), str(tmp_path), overlap, mode, fail_rank, fail_frame), nprocs=world, join=True)
+    got = [open(tmp_path / f"stopped{r}.txt").read() for r in range(world)]
+    assert all("|" in g for g in got), got                       # nobody ran to the end, nobody hung
+    frames = {int(g.split("|")[0]) for g in got}
+    assert len(frames) == 1, got                                  # ... and all in the same frame
+    if mode == "pack":
+        assert frames == {fail_frame}
+        assert "injected" in got[fail_rank]                       # the failing rank reports its own error
+    else:
+        assert any("exceeds the message capacity" in g for g in got)
