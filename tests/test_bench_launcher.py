@@ -100,6 +100,23 @@ def test_counter_runs_are_keyed_by_warmup(tmp_path):
     assert benchutil.measured_traffic(None, "k") is None and benchutil.valu_issue(None, "k", 1.0, path=str(f)) is None
 
 
+def test_counter_rates_use_the_counter_runs_own_clock():
+    """Round 3: the texture-addresser share and the vector-L1 access rate divide by the kernel's own cycles of the SAME
+    counter run (GRBM_GUI_ACTIVE, summed over 8 XCDs), not by another run's launch time at an assumed clock."""
+    run = {"kernels": {"k": {"TA_TA_BUSY_sum": 256 * 750.0, "GRBM_GUI_ACTIVE": 8 * 1000.0,
+                             "TCP_TOTAL_CACHE_ACCESSES_sum": 256 * 900.0}}}
+    assert abs(benchutil.ta_busy_frac(run, "k", launch_ms=123.0) - 0.75) < 1e-12       # the launch time is not used
+    assert abs(benchutil.l1_access_rate(run, "k") - 0.9) < 1e-12
+    assert benchutil.l1_access_rate(run, "other") is None and benchutil.l1_access_rate(None, "k") is None
+    # the committed round-3 runs carry both counters for the two neighbour kernels
+    t = json.load(open(benchutil.TRAFFIC_FILE))
+    r3 = [r for r in t["runs"] if r.get("round") == 3 and r["workload"] == "config3"]
+    assert r3
+    for r in r3:
+        for k in ("k_density_pressure_rows", "k_force_xsph_hits"):
+            assert 0.3 < benchutil.l1_access_rate(r, k) < 1.5 and 0.3 < benchutil.ta_busy_frac(r, k) < 1.0
+
+
 def test_committed_traffic_file_is_well_formed():
     t = json.load(open(benchutil.TRAFFIC_FILE))
     assert t["runs"], "profiles/traffic.json has no run"
