@@ -21,3 +21,4 @@ for wl in "config2 262144" "config2 65536" "config5 8388608"; do
   set -- $wl
   timeout -k 10 300 python bench.py --workload $1 --particles $2 --steps 30 --warmup 20 --no-cpu-baseline > $OUT/bench_$1_$2.json && python3 -c "import json; d=json.load(open('$OUT/bench_$1_$2.json')); print('$1 $2', round(d['ms_per_step'],4), d['stage_ms'])"
 done
+timeout -k 10 300 python bench.py --workload config4 --steps 10 --warmup 10 --no-cpu-baseline > $OUT/bench_config4_16777216.json && python3 -c "import json; d=json.load(open('$OUT/bench_config4_16777216.json')); print('config4', round(d['ms_per_step'],4), d['stage_ms'])"
