@@ -50,3 +50,34 @@ def test_counters_are_quoted_only_for_the_run_they_were_taken_on(capsys):
     assert 0.3 < r["ta_busy_frac"] < 1.0 and 0.3 < r["l1_accesses_per_clk_per_cu"] < 1.5
     assert r["traffic"] > r["alg_bytes_per_particle"] * d["config"]["particles"]      # wasted re-reads are visible
     assert "Infinity" in r["traffic_is"]
+
+
+def test_two_rank_bench_line_self_launched(tmp_path):
+    """`python bench.py --gpus 2` the way the driver may call it without torchrun: the parent starts the ranks; on a box
+    with one GPU they share it (said so in config.rehearsal).  Slab decomposition of config 5's geometry at a small
+    particle count; the line keeps the contract and reports what makes it trustworthy."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    # the same transport wherever the test runs: both ranks on GPU 0, host-staged messages (the RCCL path needs two GPUs
+    # and is the driver's scaling run, not a unit test)
+    env["SPH_BENCH_SHARE_GPU"], env["SPH_BENCH_BACKEND"] = "1", "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--particles", "262144", "--steps", "3",
+                          "--warmup", "3"], cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = bench.pick_json_line(out.stdout)
+    assert line is not None
+    d = json.loads(line, parse_constant=lambda c: pytest.fail(f"non-strict JSON constant {c}"))
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["world_size"] == 2 and d["scaling"] == "weak" and d["metric"] == "particle-updates/sec"
+    assert c["particles"] == 2 * 262144 and c["self_launched"] is True and c["parallelism"] == "slab2"
+    assert d["value"] is not None and d["invalid_reason"] is None
+    assert abs(d["value"] - c["particles"] * c["sub_steps"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert c["every_id_owned_once"] is True and c["halo_violations"] == 0 and c["band_misses"] == 0
+    assert c["transfer_rounds_per_exchange_rank0"] <= 2.0 and c["host_waits_per_frame_rank0"] >= 3.0
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["avg_launch_ms"] > 0
+    assert c["rehearsal"] and "share" in c["rehearsal"] and c["backend"] == "gloo"
