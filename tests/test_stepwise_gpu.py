@@ -10,6 +10,7 @@ can be compared.  -m gpu.
     (sph_upload_particles_in_place: SetData in the middle of a frame keeps the grid, as in the reference), so every
     sub-step is held to the plain 1e-5 of field scale, not only whole frames.
 """
+import numpy as np
 import pytest
 
 from sph_amd import abi, scenes
@@ -17,6 +18,7 @@ from tests.test_random_scenes_gpu import _build, _draw
 from tests.util import run_stepwise
 
 pytestmark = pytest.mark.gpu
+TOL = 1e-5          # of the field's scale, per sub-step
 
 
 def test_hit_mask_scene2_two_phase():
@@ -69,3 +71,32 @@ def test_some_cap3_case_really_overflows():
         hit += ora.read_counter(abi.CTR_BIN_OVERFLOW) > 0
         ora.destroy()
     assert hit > 0
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 513])
+def test_ragged_particle_counts_around_wave_and_workgroup_sizes(n):
+    """One particle, a wave less / exactly / more than one, a workgroup less / exactly / more than one: the last
+    workgroup is ragged (per-lane mask rows instead of the transposed wave copy, identity tile mapping), lanes past
+    the end must stay out of ballots and rankings.  Kernel by kernel against the oracle, hit mask included, plus one
+    sph_step_frame frame from the same state on a second engine (same bits as the dispatched frame)."""
+    from sph_amd.host import SPH, Scene, SpawnBox, Time
+
+    def builder(e):
+        # ~6 particles per cell at any n: a small dense blob dropping onto the floor of the default AABB
+        side = max((n / 400.0) ** (1.0 / 3.0), 0.12)
+        boxes = [SpawnBox(n, (side, side, side), 20, 0.1, 0.2, position=(0.0, 0.6 * side + 0.05, 0.0), initialVelocity=(0.3, -1.0, 0.2))]
+        f = dict(scenes.SCENE_COMMON)
+        f.update(gridResolution=24)
+        sph = SPH(e, **f, surfaceTensionCoefficient=0.1, xsphEpsilon=0.3, spawnBoxes=boxes)
+        return Scene(sph, Time(), [])
+
+    st = run_stepwise(builder, 3, tol=TOL, max_nb=512, want_overflow=False)
+    assert st["masks"] == 3
+    a, b = abi.Engine(0), abi.Engine(0)
+    sa, sb = builder(a), builder(b)
+    sa.sph.use_step_frame, sb.sph.use_step_frame = True, False
+    sa.start(); sb.start()
+    for f in range(3):
+        sa.frame(); sb.frame()
+        assert np.array_equal(a.download_particles().view(np.uint32), b.download_particles().view(np.uint32)), f"frame {f}"
+    a.destroy(); b.destroy()
